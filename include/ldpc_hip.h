@@ -1,0 +1,221 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip, the MI355X (gfx950) batched LDPC decoder.
+ *
+ * Drop-in for ONE path of mohammedmidhat/LDPC: the flooding-schedule dec()
+ * message-passing decoders and their alist loader.  Every entry point names
+ * the reference interface it replaces (file:line, relative to the reference
+ * tree).  Plain C types only; no torch / HIP types in the signatures (a
+ * hipStream_t crosses as void*).
+ *
+ * Conventions that differ from the reference on purpose:
+ *   - errors are returned as negative codes (the reference calls exit());
+ *   - there is no global state: a code and a decoder are handles, one decoder
+ *     per GPU, a decoder is not re-entrant but different decoders are
+ *     independent and host-thread-safe;
+ *   - the iteration count and the computed syndrome are outputs (the
+ *     reference keeps them in globals or drops them).
+ * Conventions kept: LLR > 0 <=> bit 0, hard decision is (sum < 0);
+ * status 0 = target syndrome reached, 1 = not reached; alist indices 1-based
+ * on disk, 0-based in memory; all decoders are syndrome decoders (zero
+ * syndrome = ordinary codeword decoding).
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_OK            0
+#define LDPC_ERR_FORMAT   -1   /* malformed alist (reference: exit(-1), GFq_LDPC.c:520-523)   */
+#define LDPC_ERR_IO       -2   /* cannot open file (reference: exit(-2), test_code_min_sum_B.c:216-219) */
+#define LDPC_ERR_NOMEM    -3   /* host or device allocation failed (reference: exit(-1), :86)  */
+#define LDPC_ERR_ARG      -4   /* bad argument / size beyond the decoder's limits              */
+#define LDPC_ERR_HIP      -5   /* HIP runtime error; text via ldpc_last_error()                */
+#define LDPC_ERR_UNSUPPORTED -6 /* algorithm/code combination not supported                    */
+
+const char *ldpc_strerror(int code);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *ldpc_last_error(void);
+/* Library version / build target string, e.g. "libldpc_hip 0.1 gfx950". */
+const char *ldpc_version(void);
+
+/* ------------------------------------------------------------------ codes */
+
+typedef struct ldpc_code ldpc_code;
+
+/* Replaces initdec() (test_code_min_sum_B.c:210-286, test_code_B.c:235-314,
+ * test_code_no_mex_B.c:244-319) and, for "n m q" headers,
+ * InitSumProductDecoderSyndrome() (GFq_LDPC.c:469-535) / the NTT initdec()
+ * (GFq_LDPC_NTT.c:547-639).  MacKay alist, padded or unpadded, tabs or
+ * spaces; like the reference, only the ROW lists define the graph (column
+ * lists are skipped) and edges keep the reference numbering: column slot k of
+ * variable v is the k-th row, scanning rows in ascending order, that holds v. */
+int ldpc_code_load_alist(const char *path, ldpc_code **out);
+
+/* Graph handed over as arrays, the shape of the WD-farm boundary
+ * (WD_farm/GFq_LDPC.c:477): row_ptr[m+1], col_idx[E] 0-based, hval[E] or NULL
+ * (binary).  q = 2 for binary codes. */
+int ldpc_code_from_csr(int n, int m, int q, const int32_t *row_ptr,
+                       const int32_t *col_idx, const int32_t *hval, ldpc_code **out);
+
+void ldpc_code_free(ldpc_code *c);
+
+int ldpc_code_n(const ldpc_code *c);     /* variables                         */
+int ldpc_code_m(const ldpc_code *c);     /* checks                            */
+int ldpc_code_q(const ldpc_code *c);     /* field order, 2 for binary         */
+int ldpc_code_edges(const ldpc_code *c); /* E                                 */
+int ldpc_code_cmax(const ldpc_code *c);  /* max column weight (from the rows) */
+int ldpc_code_rmax(const ldpc_code *c);  /* max row weight                    */
+/* Copies the CSR form out: row_ptr[m+1], col_idx[E], hval[E] (any may be NULL). */
+int ldpc_code_get_csr(const ldpc_code *c, int32_t *row_ptr, int32_t *col_idx, int32_t *hval);
+/* Copies the CSC view out: col_ptr[n+1], edge_of[E] = CSR edge id of (v, slot). */
+int ldpc_code_get_csc(const ldpc_code *c, int32_t *col_ptr, int32_t *edge_of);
+
+/* enc() (test_code_min_sum_B.c:69-79; GF: GFq_LDPC.c:299-310) on the host:
+ * s = H x over GF(q).  x[n], s[m] one symbol per int32. */
+int ldpc_code_syndrome(const ldpc_code *c, const int32_t *x, int32_t *s);
+
+/* --------------------------------------------------------------- decoders */
+
+typedef enum ldpc_alg {
+  LDPC_ALG_MINSUM_F32    = 0, /* dec(), test_code_min_sum_B.c:137-208, binary32 messages       */
+  LDPC_ALG_MINSUM_F64    = 1, /* same in binary64: the reference's own arithmetic, bit-exact   */
+  LDPC_ALG_MINSUM_Q88    = 2, /* dec(), test_code_min_sum_B_fixed.c:192-316, int16 Q8.8        */
+  LDPC_ALG_SPA_F32       = 3, /* dec(), test_code_B_float.c:134-199, binary32                  */
+  LDPC_ALG_SPA_F64       = 4, /* same in binary64                                              */
+  LDPC_ALG_SPA_TABLE_Q14 = 5, /* dec(), test_code_B.c:171-233 / test_code_no_mex_B.c:170-242   */
+  LDPC_ALG_GF2P_WHT      = 6, /* dec(), GFq_LDPC_NTT.c:437-544, GF(2^p) integer WHT domain     */
+  LDPC_ALG_GFQ_DIRECT    = 7  /* dec(), GFq_LDPC.c:356-467, GF(q) log-domain forward/backward  */
+} ldpc_alg;
+
+typedef enum ldpc_dtype {
+  LDPC_DT_F64 = 0, LDPC_DT_F32 = 1, LDPC_DT_I16 = 2, LDPC_DT_I32 = 3
+} ldpc_dtype;
+
+typedef struct ldpc_opts {
+  int32_t alg;          /* ldpc_alg                                                     */
+  int32_t device;       /* HIP device ordinal                                           */
+  int32_t max_frames;   /* frames resident per pass (0 = default 4096); larger batches
+                           are processed in passes of this size                         */
+  int32_t early_exit;   /* 1: stop a pass once every frame in it has reached its
+                           syndrome (host polls a device counter, one iteration behind);
+                           0: always run max_iter iterations (no host sync inside)      */
+  int32_t want_llr;     /* 1: keep posterior LLRs so llr_out can be filled              */
+  int32_t cn_variant;   /* 0 = default; kernel selection knob for benchmarking          */
+  int32_t reserved[10];
+} ldpc_opts;
+
+typedef struct ldpc_decoder ldpc_decoder;
+
+int  ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ldpc_decoder **out);
+void ldpc_decoder_free(ldpc_decoder *d);
+int  ldpc_decoder_max_frames(const ldpc_decoder *d);
+
+/*
+ * Batched form of  int dec(q0[], s[], loop_max, x[])  (all binary variants)
+ * and of dec(logfna, z, loop_max) (GFq_LDPC.c:356, GFq_LDPC_NTT.c:437).
+ *
+ *  llr       [nframes][n]      binary; llr_dtype one of F64/F32/I16/I32:
+ *                                MINSUM/SPA float: F64 or F32 values;
+ *                                MINSUM_Q88: I16 raw Q8.8 (value*256), or F64/F32
+ *                                  values which are put on the Q8.8 grid with the
+ *                                  reference's float_to_fix() (_fixed.c:43-53) as
+ *                                  its bsc() does (:117-120);
+ *                                SPA_TABLE_Q14: I32 raw Q8.14 (float2fix,
+ *                                  test_code_B.c:36-43) or F64 values (converted
+ *                                  with float2fix).
+ *            [nframes][n][q]   non-binary: log-probabilities per symbol value;
+ *                                GF2P_WHT: I32 raw log2-domain Q.14
+ *                                  (GFq_LDPC_NTT.c:312) or F64 log2 values;
+ *                                GFQ_DIRECT: F64/F32 natural-log values.
+ *  syndrome  [nframes][m] one symbol per byte, or NULL = all-zero syndrome
+ *  bits_out  [nframes][n] one symbol per byte   (reference global tmp_bit / tmp_x)
+ *  iters_out [nframes]  iterations executed: loop+1 at the successful exit,
+ *                       0 for MINSUM_Q88's "already a codeword" pre-check
+ *                       (_fixed.c:198-207), max_iter when not converged
+ *  synd_out  [nframes][m] H * bits_out          (reference global tmp_s / tmp_z)
+ *  status_out[nframes]  0 converged, 1 not (dec()'s return value)
+ *  llr_out   [nframes][n] float posterior sums of the iteration that produced
+ *                       bits_out (binary algorithms; needs opts.want_llr)
+ * Any output pointer may be NULL.  Host pointers.  Returns LDPC_OK or <0.
+ */
+int ldpc_decode_batch(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                      const uint8_t *syndrome, int max_iter,
+                      uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
+                      int32_t *status_out, float *llr_out);
+
+/* Same with DEVICE pointers (buffers resident in HBM) on `stream`
+ * (a hipStream_t, NULL = default stream).  nframes <= ldpc_decoder_max_frames().
+ * Asynchronous when opts.early_exit == 0; otherwise returns after the pass. */
+int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                             const uint8_t *syndrome, int max_iter,
+                             uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
+                             int32_t *status_out, float *llr_out, void *stream);
+
+/* Single-frame MINSUM_Q88 decode that also writes the Verilog message trace
+ * of test_code_min_sum_B_fixed.c (:205 "already cw", :245-260 the v2c dump,
+ * :288-296 the c2v dump; one "%08x" line per message per iteration) to
+ * trace_path.  circ_size is the reference's global of that name (:40, 128
+ * there).  The messages are read back from the GPU after each pass; the host
+ * only orders and formats them.  Returns LDPC_ERR_UNSUPPORTED for a code on
+ * which the reference's dump loops index past a row (its QC assumption).
+ * Host pointers; synchronous. */
+int ldpc_decode_trace_q88(ldpc_decoder *d, const void *llr, int llr_dtype, const uint8_t *syndrome,
+                          int max_iter, uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
+                          int32_t *status_out, const char *trace_path, int circ_size);
+
+/* Counters of the last ldpc_decode_batch*_ call (for benchmarks):
+ * iterations actually executed per pass, kernel launches. */
+int ldpc_decoder_last_iterations(const ldpc_decoder *d);
+
+/* ------------------------------------------- reference-shaped entry points
+ * Same names, argument order and meaning as the reference's C harness
+ * functions; `errors` is the caller's double[2] = {not converged, converged to
+ * a word != x}.  They return LDPC_OK or a negative code instead of void.
+ * The graph/decoder for `code_filename` is cached per process and device 0 is
+ * used (set LDPC_HIP_DEVICE to override).                                   */
+
+/* test_code_min_sum_B(), test_code_min_sum_B.c:331-359 (single frame, caller's x,s,y,q0) */
+int test_code_min_sum_B(const char *code_filename, int iteration, int *x, int *s, int *y,
+                        double *q0, double *errors);
+/* test_code_min_sum_B_cw_noise_gen(), test_code_min_sum_B.c:288-329 (Monte Carlo on a BSC) */
+int test_code_min_sum_B_cw_noise_gen(const char *code_filename, int iteration, int trials,
+                                     double p_bsc, double *errors);
+/* test_code_min_sum_B() of test_code_min_sum_B_fixed.c:442-473.  The reference
+ * reuses the float function's name with one more argument; in one C library
+ * the symbol needs its own name.  Verilog_sim_filename may be NULL (no trace);
+ * otherwise the message trace of _fixed.c:245-260,:288-296 is written (the
+ * trace is produced by a host replay).                  */
+int test_code_min_sum_B_fixed(const char *code_filename, int iteration, int *x, int *s, int *y,
+                              double *q0, double *errors, const char *Verilog_sim_filename);
+/* test_code_min_sum_B_cw_noise_gen() of test_code_min_sum_B_fixed.c:396-440 */
+int test_code_min_sum_B_fixed_cw_noise_gen(const char *code_filename, int iteration, int trials,
+                                           double p_bsc, double *errors);
+/* test_code_B_float() / _cw_noise_gen(), test_code_B_float.c:280-351 */
+int test_code_B_float(const char *code_filename, int iteration, int *x, int *s, int *y,
+                      double *q0, double *errors);
+int test_code_B_float_cw_noise_gen(const char *code_filename, int iteration, int trials,
+                                   double p_bsc, double *errors);
+/* test_code_B(), test_code_no_mex_B.c:321-381 (table sum-product, Monte Carlo;
+ * x is drawn once, as that driver does at :339-343).  The mex variant
+ * (test_code_B.c:316-360) is the same call with H_file = "peg_16000_3_0.9.txt". */
+int test_code_B(int iteration, int trials, double p_bsc, const char *H_file, double *errors);
+/* GFq_LDPC(), GFq_LDPC.c:540-655, decode_mode 0 (synthetic symbols through the
+ * confusion-matrix channel).  The reference hard-codes "547_NB.txt"; here the
+ * code file is an argument.  p_rec_given_sent is [q*num_reads][q] row-major
+ * and is column-normalised in place like the reference (:548-558).         */
+int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
+             int num_reads, int decode_mode, double *p_rec_given_sent, double *errors);
+
+/* Seed of the library's Monte-Carlo generator (the reference uses
+ * srand(time(NULL)); 0 = seed from the clock like the reference). */
+void ldpc_set_seed(uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */

@@ -1,0 +1,741 @@
+// binary_kernels.hip.h -- gfx950 kernels of the binary flooding decoders.
+//
+// Data layout in HBM ("slab-interleaved"): frames are grouped in slabs of
+// SF = 64*V frames, V = 16 / sizeof(message) (8 for Q8.8 int16, 4 for f32 and
+// int32, 2 for f64).  Every per-node or per-edge quantity is stored as one ROW
+// per (slab, node|edge): 64 lanes x 16 bytes = 1 KiB, lane l holding frames
+// slab*SF + l*V .. +V-1.  A wavefront therefore always moves whole 1-KiB rows
+// with one 16-byte access per lane (global_load/store_dwordx4), whatever the
+// graph looks like, and node/edge indices are wave-uniform scalars.
+//
+//   q0  [slab][n][64] vec   channel LLRs
+//   msg [slab][E][64] vec   edge messages in check-major (CSR) order, used IN
+//                           PLACE: holds c2v after a check pass, v2c after a
+//                           variable pass
+//   hard[slab][n][64] u8    hard decisions, bit v of a byte = frame l*V+v
+//   synd[slab][m][64] u8    target syndrome bits, same packing
+//   fail[slab][64]   u32    per-frame "some check unsatisfied" bits (atomicOr)
+//   done[slab][64]   u8     per-frame "reached its syndrome" bits
+//
+// One decoding iteration = vn_kernel (variable pass, also emits the previous
+// iteration's hard decisions) + cn_kernel (check pass, also tests the syndrome
+// of those hard decisions) + mark_kernel (per-frame bookkeeping).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace ldpc {
+
+enum { ALG_MS = 0, ALG_MSQ = 1, ALG_SPA = 2, ALG_TAB = 3 };
+
+template <typename T> struct MT;
+template <> struct MT<short> {
+  static constexpr int V = 8;
+  typedef short vec __attribute__((ext_vector_type(8)));
+  typedef int acc;
+};
+template <> struct MT<int> {
+  static constexpr int V = 4;
+  typedef int vec __attribute__((ext_vector_type(4)));
+  typedef int acc;
+};
+template <> struct MT<float> {
+  static constexpr int V = 4;
+  typedef float vec __attribute__((ext_vector_type(4)));
+  typedef float acc;
+};
+template <> struct MT<double> {
+  static constexpr int V = 2;
+  typedef double vec __attribute__((ext_vector_type(2)));
+  typedef double acc;
+};
+
+// Q8.8 limits in raw units (value*256): float_to_fix() saturates to
+// [-128, +127] (test_code_min_sum_B_fixed.c:43-53), min_msg starts at 200 (:270)
+#define Q88_POS_MAX 32512
+#define Q88_NEG_MIN (-32768)
+#define Q88_CAP200 51200
+// Q8.14 table size (test_code_B.c:27-31)
+#define TAB_LEVELS (1 << 22)
+
+struct Graph {
+  const int32_t *row_ptr;   // [m+1]
+  const int32_t *col_idx;   // [E]
+  const int32_t *col_ptr;   // [n+1]
+  const int32_t *edge_of;   // [E]
+  int n, m, E;
+};
+
+struct Tables {           // SPA_TABLE_Q14 only
+  const int32_t *flogtanh;
+  const int32_t *fgallag;
+};
+
+// ---------------------------------------------------------------- helpers
+
+template <int ALG, typename T>
+__device__ __forceinline__ T vn_store_value(typename MT<T>::acc x) {
+  if (ALG == ALG_MSQ) {
+    // magnitude = float_to_fix(|qout|): saturate at +127.0 either sign
+    int v = (int)x;
+    v = v > Q88_POS_MAX ? Q88_POS_MAX : v;
+    v = v < -Q88_POS_MAX ? -Q88_POS_MAX : v;
+    return (T)v;
+  }
+  return (T)x;
+}
+
+__device__ __forceinline__ int wave_id_uniform() {
+  return __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+}
+
+// ------------------------------------------------------- variable-node pass
+//
+// Restates the VN loop and the posterior loop of dec()
+// (test_code_min_sum_B.c:144-160 and :189-197): sum = q0 + sum_k c2v_k in
+// column-slot order, v2c_k = sum - c2v_k.  Because the posterior of iteration
+// t is the same sum the VN pass of iteration t+1 starts from, the hard
+// decision of iteration t is produced here, one pass later.
+//   FIRST: c2v are all zero (first iteration, memset at :141) -> no msg reads
+//   STORE: false for the closing posterior-only pass
+//   DVB:   compile-time bound on the column weight held in registers
+//          (0 = any weight, two passes over the rows)
+template <typename T, int ALG, int DVB, bool FIRST, bool STORE>
+__global__ __launch_bounds__(256) void vn_kernel(
+    Graph g, int nslab, const typename MT<T>::vec *__restrict__ q0,
+    typename MT<T>::vec *__restrict__ msg, uint8_t *__restrict__ hard,
+    const uint8_t *__restrict__ done, typename MT<T>::vec *__restrict__ post) {
+  typedef typename MT<T>::vec vec;
+  typedef typename MT<T>::acc acc;
+  constexpr int V = MT<T>::V;
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id_uniform();
+  const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+  const long items = (long)g.n * nslab;
+
+  for (long item = wave; item < items; item += nwaves) {
+    const int i = (int)(item / nslab);
+    const int b = (int)(item - (long)i * nslab);
+    const int p0 = g.col_ptr[i];
+    const int dv = g.col_ptr[i + 1] - p0;
+    vec *mrow = msg + (size_t)b * g.E * 64 + lane;
+    const size_t vrow = ((size_t)b * g.n + i) * 64 + lane;
+    const vec q = q0[vrow];
+    acc S[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) S[v] = (acc)q[v];
+
+    if constexpr (DVB > 0) {
+      int e[DVB];
+      vec c[DVB];
+#pragma unroll
+      for (int k = 0; k < DVB; k++) {
+        if (k < dv) {
+          e[k] = g.edge_of[p0 + k];
+          if (!FIRST) c[k] = mrow[(size_t)e[k] * 64];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DVB; k++) {
+        if (k < dv && !FIRST) {
+#pragma unroll
+          for (int v = 0; v < V; v++) S[v] = S[v] + (acc)c[k][v];
+        }
+      }
+      if (STORE) {
+#pragma unroll
+        for (int k = 0; k < DVB; k++) {
+          if (k < dv) {
+            vec o;
+#pragma unroll
+            for (int v = 0; v < V; v++)
+              o[v] = vn_store_value<ALG, T>(FIRST ? S[v] : S[v] - (acc)c[k][v]);
+            mrow[(size_t)e[k] * 64] = o;
+          }
+        }
+      }
+    } else {
+      if (!FIRST) {
+        for (int k = 0; k < dv; k++) {
+          const vec c = mrow[(size_t)g.edge_of[p0 + k] * 64];
+#pragma unroll
+          for (int v = 0; v < V; v++) S[v] = S[v] + (acc)c[v];
+        }
+      }
+      if (STORE) {
+        for (int k = 0; k < dv; k++) {
+          vec *p = mrow + (size_t)g.edge_of[p0 + k] * 64;
+          vec o;
+          if (FIRST) {
+#pragma unroll
+            for (int v = 0; v < V; v++) o[v] = vn_store_value<ALG, T>(S[v]);
+          } else {
+            const vec c = *p;
+#pragma unroll
+            for (int v = 0; v < V; v++) o[v] = vn_store_value<ALG, T>(S[v] - (acc)c[v]);
+          }
+          *p = o;
+        }
+      }
+    }
+
+    // hard decision (sum < 0), frozen for frames that already reached their syndrome
+    unsigned hb = 0;
+#pragma unroll
+    for (int v = 0; v < V; v++) hb |= (S[v] < 0 ? 1u : 0u) << v;
+    const unsigned dm = done[b * 64 + lane];
+    if (dm) hb = (hard[vrow] & dm) | (hb & ~dm);
+    hard[vrow] = (uint8_t)hb;
+
+    if (post) {   // posterior of the frames still running
+      vec o = post[vrow];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        if (!((dm >> v) & 1)) {
+          if (ALG == ALG_MSQ) {   // sum = float_to_fix(sum), _fixed.c:303
+            int s = (int)S[v];
+            s = s > Q88_POS_MAX ? Q88_POS_MAX : s;
+            s = s < Q88_NEG_MIN ? Q88_NEG_MIN : s;
+            // an int16 row cannot hold it when T is short and s == ... it can: range fits int16
+            o[v] = (T)s;
+          } else {
+            o[v] = (T)S[v];
+          }
+        }
+      }
+      post[vrow] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------- check-node math
+
+template <int ALG, typename A> struct CnState;
+
+// min-sum (test_code_min_sum_B.c:162-187): out_k = +-min(200, min_{l!=k}|v_l|)
+template <typename A> struct CnStateMin {
+  A m1, m2;
+  __device__ __forceinline__ void init(A big) { m1 = big; m2 = big; }
+  __device__ __forceinline__ void add(A a) {
+    A hi = a > m1 ? a : m1;       // max(m1, a)
+    m2 = hi < m2 ? hi : m2;
+    m1 = a < m1 ? a : m1;
+  }
+  __device__ __forceinline__ A others(A a) const { return a == m1 ? m2 : m1; }
+};
+
+__device__ __forceinline__ float spa_logtanh2(float a) { return logf(tanhf(a * 0.5f)); }
+__device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
+__device__ __forceinline__ float spa_atanh2exp(float x) { float e = expf(x); return logf((1.0f + e) / (1.0f - e)); }
+__device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
+
+// Flogtanh / Fgallag (test_code_B.c:76-90)
+__device__ __forceinline__ int tab_logtanh(const Tables &t, int a) {
+  return ((unsigned)a >= (unsigned)TAB_LEVELS) ? 0 : t.flogtanh[a];
+}
+__device__ __forceinline__ int tab_gallag(const Tables &t, int x) {
+  // x <= 0 by construction (sum of non-positive table values)
+  if (x <= -TAB_LEVELS || x > 0) return 0;
+  return t.fgallag[-x];
+}
+
+// Processes one check for one lane (V frames).  `row(k)` returns the k-th v2c
+// row of this check for this lane (LDS or global), `emit(k, vec)` stores c2v.
+template <typename T, int ALG, typename RowFn, typename EmitFn>
+__device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables &tab,
+                                           RowFn row, EmitFn emit) {
+  typedef typename MT<T>::vec vec;
+  typedef typename MT<T>::acc acc;
+  constexpr int V = MT<T>::V;
+  unsigned sg = sbits;                 // bit v: s_j ^ XOR of v2c signs  (sgnprod, :163-166)
+  if constexpr (ALG == ALG_MS || ALG == ALG_MSQ) {
+    CnStateMin<acc> st[V];
+    const acc big = ALG == ALG_MSQ ? (acc)Q88_CAP200 : (acc)200;
+#pragma unroll
+    for (int v = 0; v < V; v++) st[v].init(big);
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc xv = (acc)x[v];
+        const bool neg = xv < 0;
+        st[v].add(neg ? -xv : xv);
+        sg ^= (neg ? 1u : 0u) << v;
+      }
+    }
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+      vec o;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc xv = (acc)x[v];
+        const bool neg = xv < 0;
+        const acc mag = st[v].others(neg ? -xv : xv);
+        const bool flip = (((sg >> v) & 1u) != 0) != neg;   // sgnprod != Sgntin[j][k]
+        o[v] = (T)(flip ? -mag : mag);
+      }
+      emit(k, o);
+    }
+  } else if constexpr (ALG == ALG_SPA) {
+    // test_code_B_float.c:159-178
+    acc lp[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) lp[v] = 0;
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc xv = (acc)x[v];
+        const bool neg = xv < 0;
+        lp[v] = lp[v] + spa_logtanh2(neg ? -xv : xv);
+        sg ^= (neg ? 1u : 0u) << v;
+      }
+    }
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+      vec o;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc xv = (acc)x[v];
+        const bool neg = xv < 0;
+        const acc tout = spa_atanh2exp(lp[v] - spa_logtanh2(neg ? -xv : xv));
+        const bool flip = (((sg >> v) & 1u) != 0) != neg;
+        o[v] = (T)(flip ? -tout : tout);
+      }
+      emit(k, o);
+    }
+  } else {   // ALG_TAB, test_code_B.c:195-213
+    int lp[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) lp[v] = 0;
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const int xv = (int)x[v];
+        const bool neg = xv < 0;
+        lp[v] += tab_logtanh(tab, neg ? -xv : xv);
+        sg ^= (neg ? 1u : 0u) << v;
+      }
+    }
+    for (int k = 0; k < dc; k++) {
+      const vec x = row(k);
+      vec o;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const int xv = (int)x[v];
+        const bool neg = xv < 0;
+        const int tout = tab_gallag(tab, lp[v] - tab_logtanh(tab, neg ? -xv : xv));
+        const bool flip = (((sg >> v) & 1u) != 0) != neg;
+        o[v] = (T)(flip ? -tout : tout);
+      }
+      emit(k, o);
+    }
+  }
+}
+
+// ----------------------------------------------------------- check-node pass
+//
+// One wavefront per block; the wave owns checks c, c+WPS, ... of ONE slab so
+// that its syndrome-failure bits can be accumulated in a register and pushed
+// with a single atomicOr row at the end.  The dc rows of a check are staged in
+// a wave-private LDS region [rmax][64 lanes][16 B] (lane-private columns, so no
+// barrier is needed): either through registers (DMA = false) or with the
+// gfx950 direct global->LDS load (DMA = true, global_load_lds_dwordx4: the LDS
+// destination is wave-uniform base + lane*16, which is exactly this layout).
+//
+// Fused into the same pass: the syndrome test of the hard decisions written by
+// the preceding vn_kernel (enc() + HamDist(), test_code_min_sum_B.c:200-203).
+template <typename T, int ALG, bool DMA>
+__global__ __launch_bounds__(64) void cn_kernel(
+    Graph g, int nslab, typename MT<T>::vec *__restrict__ msg,
+    const uint8_t *__restrict__ hard, const uint8_t *__restrict__ synd,
+    uint32_t *__restrict__ fail, Tables tab) {
+  typedef typename MT<T>::vec vec;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  vec *lds = reinterpret_cast<vec *>(lds_raw);
+  const int lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = (int)gridDim.x / nslab;
+  unsigned failacc = 0;
+
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    if (DMA) {
+      for (int k = 0; k < dc; k++)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(rows + (size_t)k * 64),
+            (__attribute__((address_space(3))) void *)(lds + k * 64), 16, 0, 0);
+      for (int k = 0; k < dc; k++) par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      for (int k = 0; k < dc; k++) lds[k * 64 + lane] = rows[(size_t)k * 64];
+      for (int k = 0; k < dc; k++) par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+    }
+    failacc |= par;
+    cn_compute<T, ALG>(
+        dc, sb, tab, [&](int k) { return lds[k * 64 + lane]; },
+        [&](int k, vec o) { rows[(size_t)k * 64] = o; });
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
+// Same pass without LDS: rows are read twice from global memory (second read
+// normally served by L2).  Used when rmax KiB does not fit in LDS, and as the
+// A/B baseline for the staged kernel.
+template <typename T, int ALG>
+__global__ __launch_bounds__(256) void cn_reload_kernel(
+    Graph g, int nslab, typename MT<T>::vec *__restrict__ msg,
+    const uint8_t *__restrict__ hard, const uint8_t *__restrict__ synd,
+    uint32_t *__restrict__ fail, Tables tab) {
+  typedef typename MT<T>::vec vec;
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int nw = (int)((gridDim.x * blockDim.x) >> 6);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = nw / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    for (int k = 0; k < dc; k++) par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+    failacc |= par;
+    cn_compute<T, ALG>(
+        dc, sb, tab, [&](int k) { return rows[(size_t)k * 64]; },
+        [&](int k, vec o) { rows[(size_t)k * 64] = o; });
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
+// Register-resident variant for row weights <= RB: the whole check lives in
+// VGPRs between the load and the store (no LDS, no second read).
+template <typename T, int ALG, int RB>
+__global__ __launch_bounds__(256) void cn_reg_kernel(
+    Graph g, int nslab, typename MT<T>::vec *__restrict__ msg,
+    const uint8_t *__restrict__ hard, const uint8_t *__restrict__ synd,
+    uint32_t *__restrict__ fail, Tables tab) {
+  typedef typename MT<T>::vec vec;
+  typedef typename MT<T>::acc acc;
+  constexpr int V = MT<T>::V;
+  static_assert(ALG == ALG_MS || ALG == ALG_MSQ, "register variant is min-sum only");
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int nw = (int)((gridDim.x * blockDim.x) >> 6);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = nw / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb, sg = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    vec x[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++)
+      if (k < dc) {
+        x[k] = rows[(size_t)k * 64];
+        par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+      }
+    failacc |= par;
+    CnStateMin<acc> st[V];
+    const acc big = ALG == ALG_MSQ ? (acc)Q88_CAP200 : (acc)200;
+#pragma unroll
+    for (int v = 0; v < V; v++) st[v].init(big);
+#pragma unroll
+    for (int k = 0; k < RB; k++)
+      if (k < dc) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          const acc xv = (acc)x[k][v];
+          const bool neg = xv < 0;
+          st[v].add(neg ? -xv : xv);
+          sg ^= (neg ? 1u : 0u) << v;
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < RB; k++)
+      if (k < dc) {
+        vec o;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          const acc xv = (acc)x[k][v];
+          const bool neg = xv < 0;
+          const acc mag = st[v].others(neg ? -xv : xv);
+          const bool flip = (((sg >> v) & 1u) != 0) != neg;
+          o[v] = (T)(flip ? -mag : mag);
+        }
+        rows[(size_t)k * 64] = o;
+      }
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
+// Closing syndrome pass: sout = H * hard (the reference's tmp_s) and
+// fail |= sout ^ target.  enc() + HamDist(), test_code_min_sum_B.c:200-203.
+__global__ __launch_bounds__(256) void synd_kernel(Graph g, int nslab,
+                                                   const uint8_t *__restrict__ hard,
+                                                   const uint8_t *__restrict__ synd,
+                                                   uint8_t *__restrict__ sout,
+                                                   uint32_t *__restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int nw = (int)((gridDim.x * blockDim.x) >> 6);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = nw / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;
+  const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    unsigned par = 0;
+    for (int k = 0; k < dc; k++) par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+    const size_t o = ((size_t)b * g.m + j) * 64 + lane;
+    if (sout) sout[o] = (uint8_t)par;
+    failacc |= par ^ (synd ? synd[o] : 0u);
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
+// ------------------------------------------------------ per-frame bookkeeping
+
+// done/fail/iters initialisation for a pass of `nframes` frames.
+__global__ void init_state_kernel(int nslab, int V, int nframes, uint32_t *fail, uint8_t *done,
+                                  int32_t *iters) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nslab * 64) return;
+  unsigned invalid = 0;
+  for (int v = 0; v < V; v++) {
+    iters[idx * V + v] = -1;
+    if (idx * V + v >= nframes) invalid |= 1u << v;
+  }
+  fail[idx] = 0;
+  done[idx] = (uint8_t)invalid;   // padding frames are frozen from the start
+}
+
+// After a syndrome test of the hard decisions of iteration `it`: frames whose
+// fail bits stayed clear have converged at `it` (dec() returns 0 there).
+// ignore != 0 discards the test (the float decoders have no iteration-0 check).
+__global__ void mark_kernel(int nslab, int V, int nframes, int it, int ignore, uint32_t *fail,
+                            uint8_t *done, int32_t *iters, int32_t *remaining) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int rem = 0;
+  if (idx < nslab * 64) {
+    const unsigned f = fail[idx];
+    fail[idx] = 0;
+    unsigned d = done[idx];
+    const unsigned all = (1u << V) - 1u;
+    if (!ignore) {
+      const unsigned newly = ~f & ~d & all;
+      if (newly) {
+        for (int v = 0; v < V; v++)
+          if ((newly >> v) & 1u) iters[idx * V + v] = it;
+        d |= newly;
+        done[idx] = (uint8_t)d;
+      }
+    }
+    rem = __popc(~d & all);
+  }
+  // block reduction -> one atomic per block
+  for (int o = 32; o > 0; o >>= 1) rem += __shfl_down(rem, o);
+  __shared__ int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rem;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += part[k];
+    if (tot) atomicAdd(remaining, tot);
+  }
+}
+
+// ---------------------------------------------------------- ingest / egress
+
+// float_to_fix() (test_code_min_sum_B_fixed.c:43-53) to raw Q8.8
+__device__ __forceinline__ int q88_from_real(double x) {
+  double r = round(x * 256.0);
+  if (r > 127.0 * 256.0) r = 127.0 * 256.0;
+  if (r < -128.0 * 256.0) r = -128.0 * 256.0;
+  return (int)r;
+}
+// float2fix() (test_code_B.c:36-43) to raw Q8.14
+__device__ __forceinline__ int q14_from_real(double x) {
+  if (x >= 0) return (int)(x * 16384.0 + 0.5);
+  return -(int)((-x) * 16384.0 + 0.5);
+}
+
+template <typename InT, typename T, int ALG>
+__device__ __forceinline__ T ingest_convert(InT x) {
+  if constexpr (ALG == ALG_MSQ) {
+    if constexpr (std::is_integral<InT>::value) return (T)x;   // raw Q8.8
+    else return (T)q88_from_real((double)x);
+  } else if constexpr (ALG == ALG_TAB) {
+    if constexpr (std::is_integral<InT>::value) return (T)x;   // raw Q8.14
+    else return (T)q14_from_real((double)x);
+  } else {
+    return (T)x;
+  }
+}
+
+// in [nframes][n] (frame-major, as the callers of dec() hold q0) ->
+// q0 [slab][n][64] vec.  Block = 256 threads, tile = 32 variables x one slab.
+template <typename InT, typename T, int ALG>
+__global__ __launch_bounds__(256) void ingest_kernel(const InT *__restrict__ in, int nframes, int n,
+                                                     typename MT<T>::vec *__restrict__ q0) {
+  typedef typename MT<T>::vec vec;
+  constexpr int V = MT<T>::V;
+  constexpr int SF = 64 * V;
+  constexpr int LD = SF + V;   // 16-byte pad keeps rows 16-B aligned
+  __shared__ __attribute__((aligned(16))) T tile[32 * LD];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  {
+    const int ii = tid & 31;
+    const int i = i0 + ii;
+    for (int f = tid >> 5; f < SF; f += 8) {
+      const long frame = (long)b * SF + f;
+      T val = (T)0;
+      if (frame < nframes && i < n) val = ingest_convert<InT, T, ALG>(in[frame * n + i]);
+      tile[ii * LD + f] = val;
+    }
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63;
+    for (int r = tid >> 6; r < 32; r += 4) {
+      const int i = i0 + r;
+      if (i < n) q0[((size_t)b * n + i) * 64 + lane] = *reinterpret_cast<const vec *>(&tile[r * LD + lane * V]);
+    }
+  }
+}
+
+// s [nframes][m] one bit per byte -> synd [slab][m][64] u8 (bit v = frame l*V+v)
+template <int V>
+__global__ __launch_bounds__(256) void ingest_synd_kernel(const uint8_t *__restrict__ s, int nframes,
+                                                          int m, uint8_t *__restrict__ synd) {
+  constexpr int SF = 64 * V;
+  constexpr int LD = 68;
+  __shared__ uint8_t tile[SF * LD];
+  const int b = blockIdx.y;
+  const int j0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  {
+    const int jj = tid & 63;
+    for (int f = tid >> 6; f < SF; f += 4) {
+      const long frame = (long)b * SF + f;
+      uint8_t val = 0;
+      if (frame < nframes && j0 + jj < m) val = s[frame * m + j0 + jj] & 1;
+      tile[f * LD + jj] = val;
+    }
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63;
+    for (int r = tid >> 6; r < 64; r += 4) {
+      if (j0 + r < m) {
+        unsigned byte = 0;
+#pragma unroll
+        for (int v = 0; v < V; v++) byte |= (unsigned)tile[(lane * V + v) * LD + r] << v;
+        synd[((size_t)b * m + j0 + r) * 64 + lane] = (uint8_t)byte;
+      }
+    }
+  }
+}
+
+// packed [slab][len][64] u8 -> out [nframes][len] one bit per byte
+template <int V>
+__global__ __launch_bounds__(256) void egress_bits_kernel(const uint8_t *__restrict__ packed, int nframes,
+                                                          int len, uint8_t *__restrict__ out) {
+  constexpr int SF = 64 * V;
+  constexpr int LD = 68;
+  __shared__ uint8_t tile[64 * LD];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  {
+    const int lane = tid & 63;
+    for (int r = tid >> 6; r < 64; r += 4)
+      tile[r * LD + lane] = (i0 + r < len) ? packed[((size_t)b * len + i0 + r) * 64 + lane] : 0;
+  }
+  __syncthreads();
+  {
+    const int ii = tid & 63;
+    for (int f = tid >> 6; f < SF; f += 4) {
+      const long frame = (long)b * SF + f;
+      if (frame < nframes && i0 + ii < len)
+        out[frame * len + i0 + ii] = (tile[ii * LD + f / V] >> (f % V)) & 1;
+    }
+  }
+}
+
+// post [slab][n][64] vec -> out [nframes][n] float
+template <typename T, int ALG>
+__global__ __launch_bounds__(256) void egress_post_kernel(const typename MT<T>::vec *__restrict__ post,
+                                                          int nframes, int n, float *__restrict__ out) {
+  typedef typename MT<T>::vec vec;
+  constexpr int V = MT<T>::V;
+  constexpr int SF = 64 * V;
+  constexpr int LD = SF + V;
+  __shared__ __attribute__((aligned(16))) T tile[32 * LD];
+  const int b = blockIdx.y;
+  const int i0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  {
+    const int lane = tid & 63;
+    for (int r = tid >> 6; r < 32; r += 4) {
+      const int i = i0 + r;
+      vec x;
+#pragma unroll
+      for (int v = 0; v < V; v++) x[v] = (T)0;
+      if (i < n) x = post[((size_t)b * n + i) * 64 + lane];
+      *reinterpret_cast<vec *>(&tile[r * LD + lane * V]) = x;
+    }
+  }
+  __syncthreads();
+  {
+    const int ii = tid & 31;
+    const int i = i0 + ii;
+    for (int f = tid >> 5; f < SF; f += 8) {
+      const long frame = (long)b * SF + f;
+      if (frame < nframes && i < n) {
+        float val = (float)tile[ii * LD + f];
+        if (ALG == ALG_MSQ) val *= (1.0f / 256.0f);
+        if (ALG == ALG_TAB) val *= (1.0f / 16384.0f);
+        out[frame * n + i] = val;
+      }
+    }
+  }
+}
+
+// iters/status per frame from the slab state
+__global__ void egress_state_kernel(int nframes, int V, int max_iter, const uint8_t *done,
+                                    const int32_t *iters, int32_t *iters_out, int32_t *status_out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  const int idx = f / V, v = f % V;
+  const bool ok = (done[idx] >> v) & 1;
+  if (iters_out) iters_out[f] = ok ? iters[f] : max_iter;
+  if (status_out) status_out[f] = ok ? 0 : 1;
+}
+
+}  // namespace ldpc

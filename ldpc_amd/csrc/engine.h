@@ -1,0 +1,79 @@
+// engine.h -- shared host-side plumbing of libldpc_hip: error reporting, a
+// device buffer holder and the Engine interface every algorithm implements.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+#include "graph.h"
+
+void ldpc_set_error(const std::string &s);
+
+#define HIPCHK(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      ldpc_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+      return LDPC_ERR_HIP;                                                        \
+    }                                                                             \
+  } while (0)
+
+#define LAUNCHCHK(name)                                                           \
+  do {                                                                            \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess) {                                                       \
+      ldpc_set_error(std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+      return LDPC_ERR_HIP;                                                        \
+    }                                                                             \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t want) {
+    if (want <= bytes) return LDPC_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
+      ldpc_set_error("hipMalloc of " + std::to_string(want) + " bytes failed");
+      return LDPC_ERR_NOMEM;
+    }
+    bytes = want;
+    return LDPC_OK;
+  }
+  template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
+};
+
+struct Engine {
+  virtual ~Engine() {}
+  virtual int init(const ldpc_code &c, const ldpc_opts &o) = 0;
+  // device pointers
+  virtual int decode(int nframes, const void *llr, int dt, const uint8_t *synd, int max_iter,
+                     uint8_t *bits, int32_t *iters, uint8_t *sout, int32_t *status, float *llr_out,
+                     hipStream_t st) = 0;
+  virtual size_t llr_elems_per_frame() const = 0;   // n (binary) or n*q
+  // single frame, device pointers, synchronous; writes the Verilog trace (Q8.8 engines only)
+  virtual int decode_traced(const void *, int, const uint8_t *, int, uint8_t *, int32_t *, uint8_t *,
+                            int32_t *, FILE *, int) {
+    ldpc_set_error("message trace is only available for MINSUM_Q88");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  int last_iterations = 0;
+};
+
+
+// host-built lookup tables (tables.cpp)
+void ldpc_build_spa_tables(std::vector<int32_t> &flogtanh, std::vector<int32_t> &fgallag);
+void ldpc_build_wht_tables(std::vector<int32_t> &flog, std::vector<uint32_t> &fexp);
+void ldpc_gf_tables_host(int q, int *logq, int *expq);
+int ldpc_gf_mul_host(int q, int a, int b);
+
+// gf_engine.hip
+Engine *ldpc_make_gf_engine(int alg, const ldpc_code &c);

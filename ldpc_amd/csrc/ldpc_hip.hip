@@ -1,0 +1,617 @@
+// ldpc_hip.hip -- C ABI (include/ldpc_hip.h) and host orchestration of the
+// gfx950 decoders.  One ldpc_decoder = one GPU, one resident workspace sized
+// for opts.max_frames frames; a decode call is a fixed sequence of kernel
+// launches on the caller's stream (see run_pass()).
+#include "../../include/ldpc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "binary_kernels.hip.h"
+#include "engine.h"
+#include "graph.h"
+
+// ------------------------------------------------------------------ errors
+
+static thread_local std::string g_last_error;
+
+void ldpc_set_error(const std::string &s) { g_last_error = s; }
+
+extern "C" const char *ldpc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *ldpc_strerror(int code) {
+  switch (code) {
+    case LDPC_OK: return "ok";
+    case LDPC_ERR_FORMAT: return "malformed alist / graph";
+    case LDPC_ERR_IO: return "cannot open file";
+    case LDPC_ERR_NOMEM: return "out of memory";
+    case LDPC_ERR_ARG: return "bad argument";
+    case LDPC_ERR_HIP: return "HIP runtime error";
+    case LDPC_ERR_UNSUPPORTED: return "unsupported algorithm/code combination";
+    default: return "unknown error";
+  }
+}
+
+extern "C" const char *ldpc_version(void) { return "libldpc_hip 0.1 gfx950"; }
+
+// ------------------------------------------------------------------- codes
+
+extern "C" int ldpc_code_load_alist(const char *path, ldpc_code **out) {
+  if (!path || !out) return LDPC_ERR_ARG;
+  std::unique_ptr<ldpc_code> c(new (std::nothrow) ldpc_code);
+  if (!c) return LDPC_ERR_NOMEM;
+  std::string err;
+  int rc = ldpc_parse_alist(path, *c, err);
+  if (rc != LDPC_OK) {
+    ldpc_set_error(err);
+    return rc;
+  }
+  *out = c.release();
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_code_from_csr(int n, int m, int q, const int32_t *row_ptr, const int32_t *col_idx,
+                                  const int32_t *hval, ldpc_code **out) {
+  if (!row_ptr || !col_idx || !out || n <= 0 || m <= 0 || q < 2 || q > 256) return LDPC_ERR_ARG;
+  std::unique_ptr<ldpc_code> c(new (std::nothrow) ldpc_code);
+  if (!c) return LDPC_ERR_NOMEM;
+  c->n = n;
+  c->m = m;
+  c->q = q;
+  c->row_ptr.assign(row_ptr, row_ptr + m + 1);
+  const int E = row_ptr[m];
+  if (E < 0) return LDPC_ERR_ARG;
+  c->col_idx.assign(col_idx, col_idx + E);
+  if (hval) c->hval.assign(hval, hval + E);
+  std::string err;
+  int rc = ldpc_finish_code(*c, err);
+  if (rc != LDPC_OK) {
+    ldpc_set_error(err);
+    return rc;
+  }
+  c->source = "<csr>";
+  *out = c.release();
+  return LDPC_OK;
+}
+
+extern "C" void ldpc_code_free(ldpc_code *c) { delete c; }
+extern "C" int ldpc_code_n(const ldpc_code *c) { return c ? c->n : LDPC_ERR_ARG; }
+extern "C" int ldpc_code_m(const ldpc_code *c) { return c ? c->m : LDPC_ERR_ARG; }
+extern "C" int ldpc_code_q(const ldpc_code *c) { return c ? c->q : LDPC_ERR_ARG; }
+extern "C" int ldpc_code_edges(const ldpc_code *c) { return c ? c->E() : LDPC_ERR_ARG; }
+extern "C" int ldpc_code_cmax(const ldpc_code *c) { return c ? c->cmax : LDPC_ERR_ARG; }
+extern "C" int ldpc_code_rmax(const ldpc_code *c) { return c ? c->rmax : LDPC_ERR_ARG; }
+
+extern "C" int ldpc_code_get_csr(const ldpc_code *c, int32_t *row_ptr, int32_t *col_idx, int32_t *hval) {
+  if (!c) return LDPC_ERR_ARG;
+  if (row_ptr) memcpy(row_ptr, c->row_ptr.data(), sizeof(int32_t) * (c->m + 1));
+  if (col_idx) memcpy(col_idx, c->col_idx.data(), sizeof(int32_t) * c->E());
+  if (hval) memcpy(hval, c->hval.data(), sizeof(int32_t) * c->E());
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_code_get_csc(const ldpc_code *c, int32_t *col_ptr, int32_t *edge_of) {
+  if (!c) return LDPC_ERR_ARG;
+  if (col_ptr) memcpy(col_ptr, c->col_ptr.data(), sizeof(int32_t) * (c->n + 1));
+  if (edge_of) memcpy(edge_of, c->edge_of.data(), sizeof(int32_t) * c->E());
+  return LDPC_OK;
+}
+
+int ldpc_gf_mul_host(int q, int a, int b);   // gf_engine.hip
+
+extern "C" int ldpc_code_syndrome(const ldpc_code *c, const int32_t *x, int32_t *s) {
+  if (!c || !x || !s) return LDPC_ERR_ARG;
+  const bool pow2 = (c->q & (c->q - 1)) == 0;
+  for (int j = 0; j < c->m; j++) {
+    int acc = 0;
+    for (int e = c->row_ptr[j]; e < c->row_ptr[j + 1]; e++) {
+      if (c->q == 2) {
+        acc ^= x[c->col_idx[e]] & 1;
+      } else {
+        int t = ldpc_gf_mul_host(c->q, x[c->col_idx[e]], c->hval[e]);
+        acc = pow2 ? (acc ^ t) : (acc + t) % c->q;
+      }
+    }
+    s[j] = acc;
+  }
+  return LDPC_OK;
+}
+
+// ----------------------------------------------------------------- engines
+
+static size_t dtype_size(int dt) {
+  switch (dt) {
+    case LDPC_DT_F64: return 8;
+    case LDPC_DT_F32: return 4;
+    case LDPC_DT_I16: return 2;
+    case LDPC_DT_I32: return 4;
+    default: return 0;
+  }
+}
+
+namespace {
+using namespace ldpc;
+
+constexpr int EV_RING = 4;
+
+template <typename T, int ALG>
+struct BinaryEngine : Engine {
+  typedef typename MT<T>::vec vec;
+  static constexpr int V = MT<T>::V;
+  static constexpr int SF = 64 * V;
+
+  ldpc_opts opts{};
+  int n = 0, m = 0, E = 0, cmax = 0, rmax = 0;
+  int nslab_max = 0;
+  int num_cu = 256;
+  int cn_variant = 0;
+  int vn_bucket = 0;
+  DevBuf g_row_ptr, g_col_idx, g_col_ptr, g_edge_of;
+  DevBuf q0, msg, post, hard, synd, sout, fail, done, iters, remaining, tab_lt, tab_g;
+  int32_t *h_remaining = nullptr;
+  int remaining_cap = 0;
+  hipEvent_t ev[EV_RING] = {};
+  Graph g{};
+  Tables tab{};
+
+  ~BinaryEngine() override {
+    if (h_remaining) (void)hipHostFree(h_remaining);
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+
+  size_t llr_elems_per_frame() const override { return (size_t)n; }
+
+  int upload(DevBuf &b, const std::vector<int32_t> &v) {
+    int rc = b.ensure(sizeof(int32_t) * (v.size() ? v.size() : 1));
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(b.p, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+    return LDPC_OK;
+  }
+
+  int ensure_remaining(int slots) {
+    if (slots <= remaining_cap) return LDPC_OK;
+    if (h_remaining) (void)hipHostFree(h_remaining);
+    h_remaining = nullptr;
+    int cap = slots < 256 ? 256 : slots;
+    HIPCHK(hipHostMalloc((void **)&h_remaining, sizeof(int32_t) * cap, hipHostMallocDefault));
+    int rc = remaining.ensure(sizeof(int32_t) * cap);
+    if (rc) return rc;
+    remaining_cap = cap;
+    return LDPC_OK;
+  }
+
+  int init(const ldpc_code &c, const ldpc_opts &o) override {
+    opts = o;
+    n = c.n; m = c.m; E = c.E(); cmax = c.cmax; rmax = c.rmax;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, o.device));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int mf = o.max_frames > 0 ? o.max_frames : 4096;
+    nslab_max = (mf + SF - 1) / SF;
+    int rc;
+    if ((rc = upload(g_row_ptr, c.row_ptr))) return rc;
+    if ((rc = upload(g_col_idx, c.col_idx))) return rc;
+    if ((rc = upload(g_col_ptr, c.col_ptr))) return rc;
+    if ((rc = upload(g_edge_of, c.edge_of))) return rc;
+    g.row_ptr = g_row_ptr.as<int32_t>();
+    g.col_idx = g_col_idx.as<int32_t>();
+    g.col_ptr = g_col_ptr.as<int32_t>();
+    g.edge_of = g_edge_of.as<int32_t>();
+    g.n = n; g.m = m; g.E = E;
+    const size_t rows = (size_t)nslab_max * 64;
+    if ((rc = q0.ensure(rows * n * sizeof(vec)))) return rc;
+    if ((rc = msg.ensure(rows * E * sizeof(vec)))) return rc;
+    if (o.want_llr && (rc = post.ensure(rows * n * sizeof(vec)))) return rc;
+    if ((rc = hard.ensure(rows * n))) return rc;
+    if ((rc = synd.ensure(rows * m))) return rc;
+    if ((rc = sout.ensure(rows * m))) return rc;
+    if ((rc = fail.ensure(rows * sizeof(uint32_t)))) return rc;
+    if ((rc = done.ensure(rows))) return rc;
+    if ((rc = iters.ensure(rows * V * sizeof(int32_t)))) return rc;
+    if ((rc = ensure_remaining(256))) return rc;
+    for (auto &e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    vn_bucket = cmax <= 4 ? 4 : cmax <= 8 ? 8 : cmax <= 16 ? 16 : 0;
+
+    // check-node kernel selection
+    //   0 auto, 1 LDS staged through registers, 2 two-pass reload, 3 register
+    //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA
+    cn_variant = o.cn_variant;
+    if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) cn_variant = atoi(e);
+    if (cn_variant == 0) cn_variant = 1;
+    const size_t lds_need = (size_t)rmax * 1024;
+    if ((cn_variant == 1 || cn_variant == 4) && lds_need > 160 * 1024) cn_variant = 2;
+    if (cn_variant == 3 && (rmax > 32 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 1;
+    if (cn_variant == 1 && lds_need > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void *)cn_kernel<T, ALG, false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    if (cn_variant == 4 && lds_need > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void *)cn_kernel<T, ALG, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+
+    if (ALG == ALG_TAB) {
+      std::vector<int32_t> lt, ga;
+      ldpc_build_spa_tables(lt, ga);
+      if ((rc = upload(tab_lt, lt))) return rc;
+      if ((rc = upload(tab_g, ga))) return rc;
+      tab.flogtanh = tab_lt.as<int32_t>();
+      tab.fgallag = tab_g.as<int32_t>();
+    }
+    return LDPC_OK;
+  }
+
+  template <bool FIRST, bool STORE>
+  int launch_vn(int nslab, hipStream_t st) {
+    const long items = (long)n * nslab;
+    long blocks = (items + 3) / 4;
+    const long cap = (long)num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    vec *p = opts.want_llr ? post.as<vec>() : nullptr;
+    dim3 grid((unsigned)blocks), block(256);
+#define VN_LAUNCH(B)                                                                         \
+  hipLaunchKernelGGL((vn_kernel<T, ALG, B, FIRST, STORE>), grid, block, 0, st, g, nslab,      \
+                     q0.as<vec>(), msg.as<vec>(), hard.as<uint8_t>(), done.as<uint8_t>(), p)
+    switch (vn_bucket) {
+      case 4: VN_LAUNCH(4); break;
+      case 8: VN_LAUNCH(8); break;
+      case 16: VN_LAUNCH(16); break;
+      default: VN_LAUNCH(0); break;
+    }
+#undef VN_LAUNCH
+    LAUNCHCHK("vn_kernel");
+    return LDPC_OK;
+  }
+
+  // waves per slab so that every wave gets the same number of checks
+  int balanced_wps(int nslab, long target_waves) const {
+    long wps = target_waves / nslab;
+    if (wps < 1) wps = 1;
+    if (wps > m) wps = m;
+    const long per = (m + wps - 1) / wps;
+    wps = (m + per - 1) / per;
+    return (int)wps;
+  }
+
+  int launch_cn(int nslab, const uint8_t *sy, hipStream_t st) {
+    int oversub = 1;
+    if (const char *e = getenv("LDPC_HIP_CN_OVERSUB")) oversub = atoi(e) > 0 ? atoi(e) : 1;
+    if (cn_variant == 1 || cn_variant == 4) {
+      const size_t lds = (size_t)rmax * 1024;
+      long per_cu = (160 * 1024) / (long)lds;
+      if (per_cu > 32) per_cu = 32;
+      if (per_cu < 1) per_cu = 1;
+      const int wps = balanced_wps(nslab, (long)num_cu * per_cu * oversub);
+      dim3 grid((unsigned)(wps * nslab)), block(64);
+      if (cn_variant == 1)
+        hipLaunchKernelGGL((cn_kernel<T, ALG, false>), grid, block, lds, st, g, nslab, msg.as<vec>(),
+                           hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+      else
+        hipLaunchKernelGGL((cn_kernel<T, ALG, true>), grid, block, lds, st, g, nslab, msg.as<vec>(),
+                           hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+      LAUNCHCHK("cn_kernel");
+      return LDPC_OK;
+    }
+    // 256-thread blocks, one wave per (check, slab) item
+    const int wps = balanced_wps(nslab, (long)num_cu * 16 * oversub);
+    const long waves = (long)wps * nslab;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (cn_variant == 3) {
+      if constexpr (ALG == ALG_MS || ALG == ALG_MSQ) {
+        if (rmax <= 8)
+          hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 8>), grid, block, 0, st, g, nslab, msg.as<vec>(),
+                             hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+        else if (rmax <= 16)
+          hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 16>), grid, block, 0, st, g, nslab, msg.as<vec>(),
+                             hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+        else
+          hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 32>), grid, block, 0, st, g, nslab, msg.as<vec>(),
+                             hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+      }
+      LAUNCHCHK("cn_reg_kernel");
+      return LDPC_OK;
+    }
+    hipLaunchKernelGGL((cn_reload_kernel<T, ALG>), grid, block, 0, st, g, nslab, msg.as<vec>(),
+                       hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+    LAUNCHCHK("cn_reload_kernel");
+    return LDPC_OK;
+  }
+
+  int launch_mark(int nslab, int nframes, int it, int ignore, int slot, hipStream_t st) {
+    const int threads = nslab * 64;
+    hipLaunchKernelGGL(mark_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, nslab, V, nframes, it,
+                       ignore, fail.as<uint32_t>(), done.as<uint8_t>(), iters.as<int32_t>(),
+                       remaining.as<int32_t>() + slot);
+    LAUNCHCHK("mark_kernel");
+    return LDPC_OK;
+  }
+
+  template <typename InT>
+  int launch_ingest(const void *llr, int nframes, int nslab, hipStream_t st) {
+    dim3 grid((n + 31) / 32, nslab), block(256);
+    hipLaunchKernelGGL((ingest_kernel<InT, T, ALG>), grid, block, 0, st, (const InT *)llr, nframes, n,
+                       q0.as<vec>());
+    LAUNCHCHK("ingest_kernel");
+    return LDPC_OK;
+  }
+
+  int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+             int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+             hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
+    if (nframes > nslab_max * SF || !llr || max_iter < 0 || max_iter > 65000) {
+      ldpc_set_error("nframes/max_iter out of range for this decoder");
+      return LDPC_ERR_ARG;
+    }
+    if (llr_out && !opts.want_llr) {
+      ldpc_set_error("llr_out needs opts.want_llr");
+      return LDPC_ERR_ARG;
+    }
+    const int nslab = (nframes + SF - 1) / SF;
+    const bool early = opts.early_exit != 0;
+    int rc;
+    if ((rc = ensure_remaining(max_iter + 2))) return rc;
+
+    hipLaunchKernelGGL(init_state_kernel, dim3((nslab * 64 + 255) / 256), dim3(256), 0, st, nslab, V,
+                       nframes, fail.as<uint32_t>(), done.as<uint8_t>(), iters.as<int32_t>());
+    LAUNCHCHK("init_state_kernel");
+    HIPCHK(hipMemsetAsync(remaining.p, 0, sizeof(int32_t) * (max_iter + 2), st));
+    HIPCHK(hipMemsetAsync(hard.p, 0, (size_t)nslab * 64 * n, st));
+    if (opts.want_llr) HIPCHK(hipMemsetAsync(post.p, 0, (size_t)nslab * 64 * n * sizeof(vec), st));
+
+    switch (dt) {
+      case LDPC_DT_F64: rc = launch_ingest<double>(llr, nframes, nslab, st); break;
+      case LDPC_DT_F32: rc = launch_ingest<float>(llr, nframes, nslab, st); break;
+      case LDPC_DT_I16:
+        if (ALG != ALG_MSQ) { ldpc_set_error("I16 input is for MINSUM_Q88"); return LDPC_ERR_ARG; }
+        rc = launch_ingest<short>(llr, nframes, nslab, st);
+        break;
+      case LDPC_DT_I32:
+        if (ALG != ALG_TAB && ALG != ALG_MSQ) { ldpc_set_error("I32 input is for SPA_TABLE_Q14 / MINSUM_Q88"); return LDPC_ERR_ARG; }
+        rc = launch_ingest<int>(llr, nframes, nslab, st);
+        break;
+      default: ldpc_set_error("bad llr_dtype"); return LDPC_ERR_ARG;
+    }
+    if (rc) return rc;
+    const uint8_t *sy = nullptr;
+    if (sy_in) {
+      hipLaunchKernelGGL((ingest_synd_kernel<V>), dim3((m + 63) / 64, nslab), dim3(256), 0, st, sy_in,
+                         nframes, m, synd.as<uint8_t>());
+      LAUNCHCHK("ingest_synd_kernel");
+      sy = synd.as<uint8_t>();
+    }
+
+    // iteration 1's variable pass: c2v = 0, also emits sign(q0) as "iteration 0" decisions
+    if ((rc = launch_vn<true, true>(nslab, st))) return rc;
+    bool all_done = false;
+    int executed = 0;
+    for (int t = 1; t <= max_iter; t++) {
+      if (t > 1 && (rc = launch_vn<false, true>(nslab, st))) return rc;
+      if ((rc = launch_cn(nslab, sy, st))) return rc;
+      // the check pass tested the decisions of iteration t-1; only the Q8.8
+      // decoder has an iteration-0 test (_fixed.c:198-207)
+      const int ignore = (t == 1 && ALG != ALG_MSQ) ? 1 : 0;
+      if ((rc = launch_mark(nslab, nframes, t - 1, ignore, t - 1, st))) return rc;
+      executed = t;
+      if (early) {
+        HIPCHK(hipMemcpyAsync(h_remaining + (t - 1), remaining.as<int32_t>() + (t - 1), sizeof(int32_t),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ev[(t - 1) % EV_RING], st));
+        if (t >= 2) {
+          HIPCHK(hipEventSynchronize(ev[(t - 2) % EV_RING]));
+          if (h_remaining[t - 2] == 0) { all_done = true; break; }
+        }
+      }
+    }
+    if (!all_done && max_iter > 0) {
+      if ((rc = launch_vn<false, false>(nslab, st))) return rc;   // decisions of the last iteration
+    }
+    {
+      const int wps = balanced_wps(nslab, (long)num_cu * 16);
+      const long waves = (long)wps * nslab;
+      hipLaunchKernelGGL(synd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, nslab,
+                         hard.as<uint8_t>(), sy, sout.as<uint8_t>(), fail.as<uint32_t>());
+      LAUNCHCHK("synd_kernel");
+      const int ignore = (max_iter == 0 && ALG != ALG_MSQ) ? 1 : 0;
+      if ((rc = launch_mark(nslab, nframes, max_iter, ignore, max_iter + 1, st))) return rc;
+    }
+    last_iterations = executed;
+
+    if (bits) {
+      hipLaunchKernelGGL((egress_bits_kernel<V>), dim3((n + 63) / 64, nslab), dim3(256), 0, st,
+                         hard.as<uint8_t>(), nframes, n, bits);
+      LAUNCHCHK("egress_bits_kernel");
+    }
+    if (sout_out) {
+      hipLaunchKernelGGL((egress_bits_kernel<V>), dim3((m + 63) / 64, nslab), dim3(256), 0, st,
+                         sout.as<uint8_t>(), nframes, m, sout_out);
+      LAUNCHCHK("egress_bits_kernel(synd)");
+    }
+    if (iters_out || status) {
+      hipLaunchKernelGGL(egress_state_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, nframes, V,
+                         max_iter, done.as<uint8_t>(), iters.as<int32_t>(), iters_out, status);
+      LAUNCHCHK("egress_state_kernel");
+    }
+    if (llr_out) {
+      hipLaunchKernelGGL((egress_post_kernel<T, ALG>), dim3((n + 31) / 32, nslab), dim3(256), 0, st,
+                         post.as<vec>(), nframes, n, llr_out);
+      LAUNCHCHK("egress_post_kernel");
+    }
+    return LDPC_OK;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------- decoder
+
+struct ldpc_decoder {
+  ldpc_code code;
+  ldpc_opts opts{};
+  std::unique_ptr<Engine> eng;
+  // staging for the host-pointer entry point
+  DevBuf s_llr, s_synd, s_bits, s_sout, s_iters, s_status, s_post;
+  int max_frames = 0;
+};
+
+extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ldpc_decoder **out) {
+  if (!c || !opts || !out) return LDPC_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    ldpc_set_error("no HIP device available: libldpc_hip has no CPU fallback");
+    return LDPC_ERR_HIP;
+  }
+  if (opts->device < 0 || opts->device >= ndev) {
+    ldpc_set_error("bad device ordinal");
+    return LDPC_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(opts->device));
+  std::unique_ptr<ldpc_decoder> d(new (std::nothrow) ldpc_decoder);
+  if (!d) return LDPC_ERR_NOMEM;
+  d->code = *c;
+  d->opts = *opts;
+  if (d->opts.max_frames <= 0) d->opts.max_frames = 4096;
+  d->max_frames = d->opts.max_frames;
+  const bool binary = c->q == 2;
+  switch (opts->alg) {
+    case LDPC_ALG_MINSUM_F32: if (binary) d->eng.reset(new BinaryEngine<float, ALG_MS>); break;
+    case LDPC_ALG_MINSUM_F64: if (binary) d->eng.reset(new BinaryEngine<double, ALG_MS>); break;
+    case LDPC_ALG_MINSUM_Q88:
+      if (binary) {
+        // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which
+        // does not fit an int16 Q8.8 message: such codes use int32 messages
+        if (c->min_row_weight >= 2) d->eng.reset(new BinaryEngine<short, ALG_MSQ>);
+        else d->eng.reset(new BinaryEngine<int, ALG_MSQ>);
+      }
+      break;
+    case LDPC_ALG_SPA_F32: if (binary) d->eng.reset(new BinaryEngine<float, ALG_SPA>); break;
+    case LDPC_ALG_SPA_F64: if (binary) d->eng.reset(new BinaryEngine<double, ALG_SPA>); break;
+    case LDPC_ALG_SPA_TABLE_Q14: if (binary) d->eng.reset(new BinaryEngine<int, ALG_TAB>); break;
+    case LDPC_ALG_GF2P_WHT:
+    case LDPC_ALG_GFQ_DIRECT:
+      d->eng.reset(ldpc_make_gf_engine(opts->alg, *c));
+      break;
+    default: break;
+  }
+  if (!d->eng) {
+    ldpc_set_error("algorithm not available for this code (binary algorithms need a binary alist, "
+                   "GF algorithms a non-binary one of matching field)");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  int rc = d->eng->init(d->code, d->opts);
+  if (rc) return rc;
+  *out = d.release();
+  return LDPC_OK;
+}
+
+extern "C" void ldpc_decoder_free(ldpc_decoder *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->opts.device);
+  (void)hipDeviceSynchronize();
+  delete d;
+}
+
+extern "C" int ldpc_decoder_max_frames(const ldpc_decoder *d) { return d ? d->max_frames : LDPC_ERR_ARG; }
+extern "C" int ldpc_decoder_last_iterations(const ldpc_decoder *d) {
+  return d ? d->eng->last_iterations : LDPC_ERR_ARG;
+}
+
+extern "C" int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                                        const uint8_t *syndrome, int max_iter, uint8_t *bits_out,
+                                        int32_t *iters_out, uint8_t *synd_out, int32_t *status_out,
+                                        float *llr_out, void *stream) {
+  if (!d) return LDPC_ERR_ARG;
+  if (nframes > d->max_frames) {
+    ldpc_set_error("nframes exceeds the decoder's max_frames");
+    return LDPC_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(d->opts.device));
+  return d->eng->decode(nframes, llr, llr_dtype, syndrome, max_iter, bits_out, iters_out, synd_out,
+                        status_out, llr_out, (hipStream_t)stream);
+}
+
+extern "C" int ldpc_decode_batch(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                                 const uint8_t *syndrome, int max_iter, uint8_t *bits_out,
+                                 int32_t *iters_out, uint8_t *synd_out, int32_t *status_out,
+                                 float *llr_out) {
+  if (!d || !llr || nframes < 0) return LDPC_ERR_ARG;
+  const size_t es = dtype_size(llr_dtype);
+  if (!es) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(d->opts.device));
+  const size_t per = d->eng->llr_elems_per_frame();
+  const int n = d->code.n, m = d->code.m, mf = d->max_frames;
+  int rc;
+  if ((rc = d->s_llr.ensure((size_t)mf * per * es))) return rc;
+  if (syndrome && (rc = d->s_synd.ensure((size_t)mf * m))) return rc;
+  if (bits_out && (rc = d->s_bits.ensure((size_t)mf * n))) return rc;
+  if (synd_out && (rc = d->s_sout.ensure((size_t)mf * m))) return rc;
+  if (iters_out && (rc = d->s_iters.ensure((size_t)mf * 4))) return rc;
+  if (status_out && (rc = d->s_status.ensure((size_t)mf * 4))) return rc;
+  if (llr_out && (rc = d->s_post.ensure((size_t)mf * n * 4))) return rc;
+  int worst = 0;
+  for (int f0 = 0; f0 < nframes; f0 += mf) {
+    const int nf = nframes - f0 < mf ? nframes - f0 : mf;
+    HIPCHK(hipMemcpy(d->s_llr.p, (const char *)llr + (size_t)f0 * per * es, (size_t)nf * per * es,
+                     hipMemcpyHostToDevice));
+    if (syndrome)
+      HIPCHK(hipMemcpy(d->s_synd.p, syndrome + (size_t)f0 * m, (size_t)nf * m, hipMemcpyHostToDevice));
+    rc = d->eng->decode(nf, d->s_llr.p, llr_dtype, syndrome ? d->s_synd.as<uint8_t>() : nullptr, max_iter,
+                        bits_out ? d->s_bits.as<uint8_t>() : nullptr,
+                        iters_out ? d->s_iters.as<int32_t>() : nullptr,
+                        synd_out ? d->s_sout.as<uint8_t>() : nullptr,
+                        status_out ? d->s_status.as<int32_t>() : nullptr,
+                        llr_out ? d->s_post.as<float>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if (d->eng->last_iterations > worst) worst = d->eng->last_iterations;
+    if (bits_out) HIPCHK(hipMemcpy(bits_out + (size_t)f0 * n, d->s_bits.p, (size_t)nf * n, hipMemcpyDeviceToHost));
+    if (synd_out) HIPCHK(hipMemcpy(synd_out + (size_t)f0 * m, d->s_sout.p, (size_t)nf * m, hipMemcpyDeviceToHost));
+    if (iters_out) HIPCHK(hipMemcpy(iters_out + f0, d->s_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
+    if (status_out) HIPCHK(hipMemcpy(status_out + f0, d->s_status.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
+    if (llr_out) HIPCHK(hipMemcpy(llr_out + (size_t)f0 * n, d->s_post.p, (size_t)nf * n * 4, hipMemcpyDeviceToHost));
+  }
+  d->eng->last_iterations = worst;
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_decode_trace_q88(ldpc_decoder *d, const void *llr, int llr_dtype,
+                                     const uint8_t *syndrome, int max_iter, uint8_t *bits_out,
+                                     int32_t *iters_out, uint8_t *synd_out, int32_t *status_out,
+                                     const char *trace_path, int circ_size) {
+  if (!d || !llr || !trace_path || circ_size <= 0) return LDPC_ERR_ARG;
+  const size_t es = dtype_size(llr_dtype);
+  if (!es) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(d->opts.device));
+  const int n = d->code.n, m = d->code.m;
+  int rc;
+  if ((rc = d->s_llr.ensure((size_t)d->max_frames * d->eng->llr_elems_per_frame() * es))) return rc;
+  if ((rc = d->s_synd.ensure((size_t)d->max_frames * m))) return rc;
+  if ((rc = d->s_bits.ensure((size_t)d->max_frames * n))) return rc;
+  if ((rc = d->s_sout.ensure((size_t)d->max_frames * m))) return rc;
+  if ((rc = d->s_iters.ensure((size_t)d->max_frames * 4))) return rc;
+  if ((rc = d->s_status.ensure((size_t)d->max_frames * 4))) return rc;
+  HIPCHK(hipMemcpy(d->s_llr.p, llr, (size_t)n * es, hipMemcpyHostToDevice));
+  if (syndrome) HIPCHK(hipMemcpy(d->s_synd.p, syndrome, (size_t)m, hipMemcpyHostToDevice));
+  FILE *fp = fopen(trace_path, "wt");   // test_code_min_sum_B_fixed.c:454
+  if (!fp) {
+    ldpc_set_error(std::string("cannot open trace file ") + trace_path);
+    return LDPC_ERR_IO;
+  }
+  rc = d->eng->decode_traced(d->s_llr.p, llr_dtype, syndrome ? d->s_synd.as<uint8_t>() : nullptr, max_iter,
+                             d->s_bits.as<uint8_t>(), d->s_iters.as<int32_t>(), d->s_sout.as<uint8_t>(),
+                             d->s_status.as<int32_t>(), fp, circ_size);
+  fclose(fp);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  if (bits_out) HIPCHK(hipMemcpy(bits_out, d->s_bits.p, (size_t)n, hipMemcpyDeviceToHost));
+  if (synd_out) HIPCHK(hipMemcpy(synd_out, d->s_sout.p, (size_t)m, hipMemcpyDeviceToHost));
+  if (iters_out) HIPCHK(hipMemcpy(iters_out, d->s_iters.p, 4, hipMemcpyDeviceToHost));
+  if (status_out) HIPCHK(hipMemcpy(status_out, d->s_status.p, 4, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
