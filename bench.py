@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of libldpc_hip (BASELINE.json's metric).
+
+Workload (configs[1]): PEG peg_16000_3_0.9 (n=16000, m=1600, K=14400), fixed
+point (Q8.8) min-sum -- the reference's test_code_min_sum_B_fixed.c dec() -- with
+exactly 10 iterations executed per frame: all-zero codeword, zero syndrome,
+BSC p=0.02 (above threshold, so no frame converges and early exit never
+fires), LLR = +-log((1-p)/p) on the Q8.8 grid.  A "step" decodes one batch of
+--frames frames per GPU; inputs (raw int16 LLRs, frame-major as the callers of
+dec() hold them) are resident in HBM before the timed region; outputs (decoded
+bits, iteration counts, status) are written to HBM.
+
+Prints ONE JSON line on rank 0.  value = decoded information Gbit/s over all
+ranks = K * frames * steps * ranks / seconds.  "roofline" is for the dominant
+kernel: algorithmic bytes per launch (check pass 2*E*b per frame,
+variable pass 2*E*b + n*b per frame, whole 10-iteration decode 10*(4*E*b+n*b))
+over its mean launch time from hipEvents recorded on the launch stream inside
+the timed region.  "cpu_baseline" times the CPU oracle (a port of the
+reference's dec(), oracle/ldpc_oracle.c) on a bounded sample of the same
+workload on rank 0.
+
+  python bench.py [--gpus N --steps K --warmup W --frames F --alg q88|f32 --p 0.02]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CODE = os.path.join(ROOT, "tests", "golden", "codes", "peg_16000_3_0.9.txt")
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SEED = 0x1DBC0001
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=65536, help="frames per step per GPU")
+    ap.add_argument("--alg", default="q88", choices=["q88", "f32"])
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--p", type=float, default=0.02)
+    ap.add_argument("--code", default=CODE)
+    ap.add_argument("--early-exit", type=int, default=0)
+    ap.add_argument("--cn-variant", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel hipEvents")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libldpc_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ldpc_amd
+    from ldpc_amd import ALG, DT
+
+    code = ldpc_amd.Code.from_alist(args.code)
+    n, m, E = code.n, code.m, code.E
+    K_info = n - m
+    F = args.frames
+    alg = ALG.MINSUM_Q88 if args.alg == "q88" else ALG.MINSUM_F32
+    b_msg = 2 if args.alg == "q88" else 4
+    dec = ldpc_amd.Decoder(code, alg, device=local_rank, max_frames=F, early_exit=bool(args.early_exit),
+                           cn_variant=args.cn_variant)
+
+    # synthetic frames, generated on the device (counter-based Philox stream per rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + rank)
+    L = math.log((1 - args.p) / args.p)
+    Lraw = int(round(L * 256))
+    flips = torch.rand((F, n), device=dev, generator=gen) < args.p
+    if args.alg == "q88":
+        llr = torch.where(flips, -Lraw, Lraw).to(torch.int16).contiguous()
+        dt = DT.I16
+    else:
+        llr = torch.where(flips, -L, L).to(torch.float32).contiguous()
+        dt = DT.F32
+    del flips
+    bits = torch.empty((F, n), dtype=torch.uint8, device=dev)
+    iters = torch.empty(F, dtype=torch.int32, device=dev)
+    status = torch.empty(F, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        dec.decode_device(F, llr.data_ptr(), dt, args.iters, None, bits.data_ptr(), iters.data_ptr(), None,
+                          status.data_ptr(), None, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        dec.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms_k, cnt_k = (np.zeros(4), np.zeros(4, np.int32))
+    if not args.no_profile:
+        ms_k, cnt_k = dec.profile_read()
+        dec.profile(False)
+
+    # the path's only collective: error counters (and the max of the elapsed time)
+    fails = int((status != 0).sum().item())
+    undet = int(((status == 0) & (bits.any(dim=1))).sum().item())
+    avg_it = float(iters.float().mean().item())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([fails, undet], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        fails, undet = int(c[0].item()), int(c[1].item())
+
+    if rank == 0:
+        total_frames = F * args.steps * world
+        value = K_info * total_frames / elapsed / 1e9
+        # dominant kernel
+        names = ["vn_kernel", "cn_kernel", "fused_decode_kernel", "other"]
+        per_launch_bytes = [(2 * E * b_msg + n * b_msg) * F, 2 * E * b_msg * F,
+                            args.iters * (4 * E * b_msg + n * b_msg) * F, 0]
+        roofline = None
+        if cnt_k.sum() > 0:
+            k = int(np.argmax(ms_k))
+            avg_ms = ms_k[k] / max(1, cnt_k[k])
+            ach = per_launch_bytes[k] / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt_k[k]),
+                        "algorithmic_bytes_per_launch": per_launch_bytes[k],
+                        "all_kernels_ms": {names[i]: round(float(ms_k[i]), 3) for i in range(4) if cnt_k[i]}}
+        whole = args.iters * (4 * E * b_msg + n * b_msg) * total_frames / elapsed / 1e9 / world
+        cpu = None
+        if not args.no_cpu:
+            cpu = cpu_baseline(args, n, m, K_info)
+        out = {
+            "metric": "decoded information throughput, N=16000 R=0.9 min-sum, 10 iterations",
+            "value": round(value, 3), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i16" if args.alg == "q88" else "f32", "data": "synthetic",
+            "config": {"workload": f"peg_16000_3_0.9 {'Q8.8 fixed-point' if args.alg == 'q88' else 'binary32'} "
+                                   f"min-sum, {args.iters} iterations executed per frame, BSC p={args.p}, "
+                                   f"all-zero codeword", "frames_per_step_per_gpu": F,
+                       "total_frames": total_frames, "n": n, "m": m, "edges": E,
+                       "early_exit": args.early_exit, "parallelism": f"frames sharded over {world} GPU(s)"},
+            "avg_iterations": round(avg_it, 3), "frame_failures": fails, "undetected": undet,
+            "whole_decode_algorithmic_GBps_per_gpu": round(whole, 1),
+            "whole_decode_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, n, m, K_info):
+    """The CPU oracle (port of the reference dec(), O(dc^2) check node and all) on a
+    bounded sample of the same workload, one core."""
+    from oracle.bindings import Oracle
+    ora = Oracle()
+    oc = ora.load(args.code)
+    rng = np.random.default_rng(SEED)
+    L = math.log((1 - args.p) / args.p)
+    Lq = round(L * 256) / 256.0
+    s = np.zeros(m, np.int32)
+    frames = 0
+    spent = 0.0
+    fn = (lambda q: ora.dec_minsum_fixed(oc, q, s, args.iters, None, m + 1)) if args.alg == "q88" else \
+         (lambda q: ora.dec_minsum(oc, q, s, args.iters))
+    while spent < args.cpu_seconds or frames < 8:
+        q0 = np.where(rng.random(n) < args.p, -Lq, Lq).astype(np.float64)
+        t = time.perf_counter()
+        fn(q0)
+        spent += time.perf_counter() - t
+        frames += 1
+    return {"value": round(K_info * frames / spent / 1e9, 6), "unit": "Gbit/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} frames of the same workload ({spent:.1f} s) through oracle/ldpc_oracle.c "
+                      f"(restatement of the reference dec(), -O2, one thread)"}
+
+
+if __name__ == "__main__":
+    main()

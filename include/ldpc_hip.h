@@ -172,6 +172,16 @@ int ldpc_decode_trace_q88(ldpc_decoder *d, const void *llr, int llr_dtype, const
  * iterations actually executed per pass, kernel launches. */
 int ldpc_decoder_last_iterations(const ldpc_decoder *d);
 
+/* Per-kernel timing for benchmarks (no counterpart in the reference, whose only
+ * instrumentation is clock() around the trial loop, test_code_B.c:334,354-356).
+ * With profiling enabled every launch of the decoding kernels is bracketed by a
+ * hipEvent pair on the caller's stream.  ldpc_decoder_profile_read() waits for
+ * them and returns, since the previous read, ms[4] / launches[4] summed per
+ * kernel class: 0 variable-node pass, 1 check-node pass, 2 fused
+ * whole-decode kernel, 3 other. */
+int ldpc_decoder_profile(ldpc_decoder *d, int enable);
+int ldpc_decoder_profile_read(ldpc_decoder *d, double *ms, int32_t *launches);
+
 /* ------------------------------------------- reference-shaped entry points
  * Same names, argument order and meaning as the reference's C harness
  * functions; `errors` is the caller's double[2] = {not converged, converged to

@@ -52,7 +52,7 @@ struct DevBuf {
 };
 
 struct Engine {
-  virtual ~Engine() {}
+  virtual ~Engine() { profile_free(); }
   virtual int init(const ldpc_code &c, const ldpc_opts &o) = 0;
   // device pointers
   virtual int decode(int nframes, const void *llr, int dt, const uint8_t *synd, int max_iter,
@@ -66,6 +66,48 @@ struct Engine {
     return LDPC_ERR_UNSUPPORTED;
   }
   int last_iterations = 0;
+
+  // Optional per-kernel timing (bench.py's roofline leg): hipEvent pairs around the
+  // launches of each kernel class, read back with profile_read().
+  enum { K_VN = 0, K_CN = 1, K_FUSED = 2, K_OTHER = 3, K_KINDS = 4 };
+  struct ProfRec { int kind; hipEvent_t a, b; };
+  bool profiling = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  hipEvent_t prof_event() {
+    hipEvent_t e = nullptr;
+    if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  }
+  void prof_begin(int kind, hipStream_t st) {
+    if (!profiling) return;
+    ProfRec r{kind, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, st);
+    prof_recs.push_back(r);
+  }
+  void prof_end(hipStream_t st) {
+    if (!profiling) return;
+    (void)hipEventRecord(prof_recs.back().b, st);
+  }
+  // sums elapsed ms and launch counts per kind since the last read; synchronises
+  void profile_read(double ms[K_KINDS], int count[K_KINDS]) {
+    for (int k = 0; k < K_KINDS; k++) { ms[k] = 0; count[k] = 0; }
+    for (auto &r : prof_recs) {
+      (void)hipEventSynchronize(r.b);
+      float t = 0;
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kind] += t; count[r.kind]++; }
+      prof_pool.push_back(r.a);
+      prof_pool.push_back(r.b);
+    }
+    prof_recs.clear();
+  }
+  void profile_free() {
+    double ms[K_KINDS]; int c[K_KINDS];
+    profile_read(ms, c);
+    for (auto e : prof_pool) (void)hipEventDestroy(e);
+    prof_pool.clear();
+  }
 };
 
 

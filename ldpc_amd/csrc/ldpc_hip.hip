@@ -388,12 +388,20 @@ struct BinaryEngine : Engine {
     }
 
     // iteration 1's variable pass: c2v = 0, also emits sign(q0) as "iteration 0" decisions
+    prof_begin(K_VN, st);
     if ((rc = launch_vn<true, true>(nslab, st))) return rc;
+    prof_end(st);
     bool all_done = false;
     int executed = 0;
     for (int t = 1; t <= max_iter; t++) {
-      if (t > 1 && (rc = launch_vn<false, true>(nslab, st))) return rc;
+      if (t > 1) {
+        prof_begin(K_VN, st);
+        if ((rc = launch_vn<false, true>(nslab, st))) return rc;
+        prof_end(st);
+      }
+      prof_begin(K_CN, st);
       if ((rc = launch_cn(nslab, sy, st))) return rc;
+      prof_end(st);
       // the check pass tested the decisions of iteration t-1; only the Q8.8
       // decoder has an iteration-0 test (_fixed.c:198-207)
       const int ignore = (t == 1 && ALG != ALG_MSQ) ? 1 : 0;
@@ -515,6 +523,22 @@ extern "C" void ldpc_decoder_free(ldpc_decoder *d) {
   (void)hipSetDevice(d->opts.device);
   (void)hipDeviceSynchronize();
   delete d;
+}
+
+extern "C" int ldpc_decoder_profile(ldpc_decoder *d, int enable) {
+  if (!d) return LDPC_ERR_ARG;
+  d->eng->profiling = enable != 0;
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_decoder_profile_read(ldpc_decoder *d, double *ms, int32_t *launches) {
+  if (!d || !ms || !launches) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(d->opts.device));
+  double t[Engine::K_KINDS];
+  int c[Engine::K_KINDS];
+  d->eng->profile_read(t, c);
+  for (int k = 0; k < Engine::K_KINDS; k++) { ms[k] = t[k]; launches[k] = c[k]; }
+  return LDPC_OK;
 }
 
 extern "C" int ldpc_decoder_max_frames(const ldpc_decoder *d) { return d ? d->max_frames : LDPC_ERR_ARG; }

@@ -74,6 +74,8 @@ def load_library():
     L.ldpc_decode_batch.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp]
     L.ldpc_decode_batch_device.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ldpc_decode_trace_q88.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, vp, cp, ip]
+    L.ldpc_decoder_profile.argtypes = [vp, ip]
+    L.ldpc_decoder_profile_read.argtypes = [vp, vp, vp]
     L.ldpc_set_seed.argtypes = [C.c_uint64]
     L.ldpc_set_seed.restype = None
     dp, intp = C.POINTER(C.c_double), C.POINTER(C.c_int)
@@ -237,6 +239,16 @@ class Decoder:
                                       _ptr(bits), _ptr(iters), _ptr(synd), _ptr(status),
                                       os.fsencode(trace_path), int(circ_size)))
         return dict(bits=bits, synd=synd, iters=int(iters[0]), status=int(status[0]))
+
+    def profile(self, enable=True):
+        check(load_library().ldpc_decoder_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """-> (ms[4], launches[4]) per kernel class: vn, cn, fused, other."""
+        ms = np.zeros(4, np.float64)
+        cnt = np.zeros(4, np.int32)
+        check(load_library().ldpc_decoder_profile_read(self._h, _ptr(ms), _ptr(cnt)))
+        return ms, cnt
 
     @property
     def last_iterations(self):
