@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the Monte-Carlo sharding (frame ranges,
+sharding-independent frame seeds, the counter all-reduce)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ldpc_amd.sharding import frame_range, frame_seed, reduce_counters, reduce_max
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frame_range(total, rank, world)
+    # stand-in for the decode of frames lo..hi: per-frame outcome derived from the frame seed
+    fails = undet = 0
+    hist = np.zeros(11, np.int64)
+    for f in range(lo, hi):
+        r = np.random.default_rng(frame_seed(0x1DBC0001, f)).integers(0, 100)
+        fails += r < 10
+        undet += r == 10
+        hist[r % 11] += 1
+    c = reduce_counters(np.concatenate([[fails, undet, hi - lo], hist]))
+    t = reduce_max(1.0 + rank)
+    dist.barrier()
+    if rank == 0:
+        np.save(out, np.concatenate([c, [t]]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduce_equals_single_rank(tmp_path):
+    from ldpc_amd.sharding import frame_range, frame_seed
+    total = 1001
+    out = str(tmp_path / "c.npy")
+    mp.spawn(_worker, args=(2, _free_port(), total, out), nprocs=2, join=True)
+    got = np.load(out)
+    fails = undet = 0
+    hist = np.zeros(11, np.int64)
+    for f in range(total):
+        r = np.random.default_rng(frame_seed(0x1DBC0001, f)).integers(0, 100)
+        fails += r < 10
+        undet += r == 10
+        hist[r % 11] += 1
+    assert got[:3].tolist() == [fails, undet, total]
+    assert np.array_equal(got[3:14], hist)
+    assert got[14] == 2.0
+    # ranges tile [0, total) for any world size
+    for w in (1, 2, 3, 8):
+        r = [frame_range(total, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
