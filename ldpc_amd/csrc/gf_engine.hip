@@ -1,8 +1,684 @@
-// gf_engine.hip -- non-binary engines (GF(2^p) WHT-domain, GF(q) direct).
+// gf_engine.hip -- non-binary engines of libldpc_hip (gfx950).
+//
+//   LDPC_ALG_GF2P_WHT   dec() of GFq_LDPC_NTT.c:437-544: GF(2^p), all-integer
+//                       log2-domain messages, check node in the Walsh-Hadamard
+//                       domain through two lookup tables.  Bit-exact.
+//   LDPC_ALG_GFQ_DIRECT dec() of GFq_LDPC.c:356-467: GF(q) (prime q by mod-q
+//                       arithmetic :22-24, 2^p by tables), binary64 natural-log
+//                       messages, forward/backward (sigma/rho) check node.
+//
+// Data layout in HBM: every per-edge / per-variable pmf is stored
+// [edge|variable][frame][Q] with the frame count padded to a multiple of
+// G = 64 / Q.  One wavefront works on ONE node for G consecutive frames: lane
+// l = g*Q + a holds symbol value a of frame g, so a wave moves G*Q contiguous
+// values per access, node indices and GF coefficients are wave-uniform, and
+// everything that crosses symbol values -- the coefficient permutation
+// a -> a*h, the Walsh-Hadamard butterflies, the sigma/rho convolutions, the
+// argmax and the normalising sums -- is a cross-lane operation inside the
+// wave (ds_bpermute / shuffle-xor), with LDS holding the per-edge
+// intermediates a lane needs again in the second sweep over the check.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+
 #include "engine.h"
 
+namespace gf {
+
+constexpr int W_DECI = 14;
+constexpr int W_FMUL = 1 << W_DECI;
+constexpr int W_LEVELS = 1 << 20;   // INT 6 + DECI 14 (GFq_LDPC_NTT.c:170-175)
+
+struct GGraph {
+  const int32_t *row_ptr, *col_idx, *hval, *hinv, *col_ptr, *edge_of;
+  const uint8_t *mul;   // [Q*Q] GF multiplication table
+  int n, m, E, Q, log2q, pow2, G, Fpad;
+};
+
+struct WTab {
+  const int32_t *flog;    // [2^20]
+  const uint32_t *fexp;   // centre of a [2^21] table: fexp[i], i in [-2^20, 2^20)
+};
+
+__device__ __forceinline__ int gf_sub(const GGraph &g, int a, int b) {
+  return g.pow2 ? (a ^ b) : (a - b + 2 * g.Q) % g.Q;
+}
+__device__ __forceinline__ int gf_add(const GGraph &g, int a, int b) {
+  return g.pow2 ? (a ^ b) : (a + b) % g.Q;
+}
+
+// Flog(), GFq_LDPC_NTT.c:240-247
+__device__ __forceinline__ int w_flog(const WTab &t, int x) {
+  if (x <= 0) return -W_FMUL * 14;
+  int i = 0;
+  while (x >= W_LEVELS) { x >>= 1; i++; }
+  return t.flog[x] + (i << W_DECI);
+}
+// Fexp(x) = fexp[x] (:236).  The reference does not check the index; an index
+// outside the table is undefined behaviour there and is clamped here.
+__device__ __forceinline__ int w_fexp(const WTab &t, int x) {
+  x = x < -W_LEVELS ? -W_LEVELS : x;
+  x = x > W_LEVELS - 1 ? W_LEVELS - 1 : x;
+  return (int)t.fexp[x];
+}
+// ntt(), :118-135, one value per lane: stage b pairs lanes a and a ^ (1<<b)
+__device__ __forceinline__ int wht_lanes(int y, int a, int log2q) {
+  for (int b = 0; b < log2q; b++) {
+    const int partner = __shfl_xor(y, 1 << b);
+    y = (a & (1 << b)) ? partner - y : y + partner;
+  }
+  return y;
+}
+
+struct Lane {
+  int l, g, a, base, active;
+};
+__device__ __forceinline__ Lane lane_of(const GGraph &g) {
+  Lane L;
+  L.l = threadIdx.x & 63;
+  L.g = L.l / g.Q;
+  L.a = L.l - L.g * g.Q;
+  L.active = L.g < g.G;
+  L.base = L.active ? L.g * g.Q : 0;
+  if (!L.active) L.a = 0;
+  return L;
+}
+
+// ------------------------------------------------------------------ ingest
+
+// float2fix(), GFq_LDPC_NTT.c:183-190
+__device__ __forceinline__ int w_float2fix(double x) {
+  if (x >= 0) return (int)(x * W_FMUL + 0.5);
+  return -(int)((-x) * W_FMUL + 0.5);
+}
+
+// in [F][n][Q] (frame-major, as the callers hold logfna per frame) -> fna [n][Fpad][Q]
+template <typename InT, typename T, bool WHT>
+__global__ void gf_ingest_kernel(const InT *__restrict__ in, int nframes, GGraph g, T *__restrict__ fna) {
+  const size_t total = (size_t)g.n * g.Fpad * g.Q;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int a = (int)(idx % g.Q);
+    const size_t r = idx / g.Q;
+    const int f = (int)(r % g.Fpad);
+    const int i = (int)(r / g.Fpad);
+    T v = (T)0;
+    if (f < nframes) {
+      const InT x = in[((size_t)f * g.n + i) * g.Q + a];
+      if constexpr (WHT && !std::is_integral<InT>::value) v = (T)w_float2fix((double)x);
+      else v = (T)x;
+    }
+    fna[idx] = v;
+  }
+}
+
+// s [F][len] u8 -> t [len][Fpad] u8 (and back)
+__global__ void gf_sym_in_kernel(const uint8_t *__restrict__ s, int nframes, int len, int Fpad,
+                                 uint8_t *__restrict__ t) {
+  const size_t total = (size_t)len * Fpad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int f = (int)(idx % Fpad);
+    const int j = (int)(idx / Fpad);
+    t[idx] = f < nframes ? s[(size_t)f * len + j] : 0;
+  }
+}
+__global__ void gf_sym_out_kernel(const uint8_t *__restrict__ t, int nframes, int len, int Fpad,
+                                  uint8_t *__restrict__ s) {
+  const size_t total = (size_t)len * nframes;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % len);
+    const int f = (int)(idx / len);
+    s[idx] = t[(size_t)j * Fpad + f];
+  }
+}
+
+// logqa = logfna on every edge (GFq_LDPC_NTT.c:442-446, GFq_LDPC.c:361-366)
+template <typename T>
+__global__ void gf_init_kernel(GGraph g, const T *__restrict__ fna, T *__restrict__ qa) {
+  const size_t per = (size_t)g.Fpad * g.Q;
+  const size_t total = (size_t)g.E * per;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx / per);
+    qa[idx] = fna[(size_t)g.col_idx[e] * per + (idx - (size_t)e * per)];
+  }
+}
+
+// ---------------------------------------------------- GF(2^p) WHT check node
+//
+// One wave per (check j, group of G frames).  GFq_LDPC_NTT.c:449-484.
+__global__ __launch_bounds__(64) void gf2p_cn_kernel(GGraph g, WTab tab, int nfg, const int *__restrict__ qa,
+                                                     int *__restrict__ ra, const uint8_t *__restrict__ synd) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const Lane L = lane_of(g);
+  const int j = blockIdx.x / nfg, fg = blockIdx.x - j * nfg;
+  const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
+  int *fq = lds_i;              // [dc][64] scaled |WHT| value
+  int *ng = lds_i + 64 * dc;    // [dc][64] its sign
+  const int f = fg * g.G + L.g;
+  const int z = (synd && L.active) ? synd[(size_t)j * g.Fpad + f] : 0;
+  const bool live = L.l < g.G * g.Q;
+  const int half = g.log2q / 2;
+  int logprod = 0, sgnsum = 0;
+  for (int k = 0; k < dc; k++) {
+    const int e = p0 + k;
+    const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * g.Q + L.l;
+    const int x = w_fexp(tab, live ? qa[off] : 0);
+    // fQa[a*h] = Fexp(logqa[a]): position b receives from a = b * h^-1
+    int y = __shfl(x, L.base + g.mul[L.a * g.Q + g.hinv[e]]);
+    y = wht_lanes(y, L.a, g.log2q);
+    int neg = 0;
+    if (y < 0) { y = -y; neg = 1; }
+    sgnsum ^= neg;
+    y = (y + (1 << (half - 1))) >> half;
+    fq[k * 64 + L.l] = y;
+    ng[k * 64 + L.l] = neg;
+    logprod += w_flog(tab, y);
+  }
+  for (int k = 0; k < dc; k++) {
+    const int e = p0 + k;
+    const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * g.Q + L.l;
+    int r = w_fexp(tab, logprod - w_flog(tab, fq[k * 64 + L.l]) + g.log2q * W_FMUL);
+    if (ng[k * 64 + L.l] != sgnsum) r = -r;
+    r = wht_lanes(r, L.a, g.log2q);
+    // logra[a] = Flog(fRa[z - a*h])
+    const int t = __shfl(r, L.base + (z ^ g.mul[L.a * g.Q + g.hval[e]]));
+    if (live) ra[off] = w_flog(tab, t);
+  }
+}
+
+// One wave per (variable i, group of G frames): GFq_LDPC_NTT.c:486-523 (sums,
+// leave-one-out, argmax, and the per-edge normalisation fused in).
+__global__ __launch_bounds__(256) void gf2p_vn_kernel(GGraph g, WTab tab, int nfg, const int *__restrict__ fna,
+                                                      const int *__restrict__ ra, int *__restrict__ qa,
+                                                      uint8_t *__restrict__ xhat,
+                                                      const uint8_t *__restrict__ frozen) {
+  const Lane L = lane_of(g);
+  const long item = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (item >= (long)g.n * nfg) return;
+  const int i = (int)(item / nfg), fg = (int)(item - (long)i * nfg);
+  const int p0 = g.col_ptr[i], dv = g.col_ptr[i + 1] - p0;
+  const bool live = L.l < g.G * g.Q;
+  const size_t fo = (size_t)fg * g.G * g.Q + L.l;
+  int logprod = live ? fna[(size_t)i * g.Fpad * g.Q + fo] : 0;
+  for (int k = 0; k < dv; k++) {
+    const int e = g.edge_of[p0 + k];
+    logprod += live ? ra[(size_t)e * g.Fpad * g.Q + fo] : 0;
+  }
+  int maxp = -(1 << 30), arg = -1;
+  for (int t = 0; t < g.Q; t++) {
+    const int v = __shfl(logprod, L.base + t);
+    if (v > maxp) { maxp = v; arg = t; }
+  }
+  const int f = fg * g.G + L.g;
+  if (live && L.a == 0 && !frozen[f]) xhat[(size_t)i * g.Fpad + f] = (uint8_t)arg;
+  for (int k = 0; k < dv; k++) {
+    const int e = g.edge_of[p0 + k];
+    const size_t off = (size_t)e * g.Fpad * g.Q + fo;
+    int q = logprod - (live ? ra[off] : 0);
+    int sum = w_fexp(tab, q);
+    for (int b = 0; b < g.log2q; b++) sum += __shfl_xor(sum, 1 << b);
+    if (sum <= 0) sum = g.Q;
+    q -= w_flog(tab, sum);
+    if (live) qa[off] = q;
+  }
+}
+
+// ------------------------------------------------ GF(q) direct check node
+//
+// One wave per (check j, G frames).  GFq_LDPC.c:369-424: rho backward (kept in
+// LDS, lane-private), then sigma forward and the extrinsic r in one sweep.
+__global__ __launch_bounds__(64) void gfq_cn_kernel(GGraph g, int nfg, const double *__restrict__ qa,
+                                                    double *__restrict__ ra, const uint8_t *__restrict__ synd) {
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  const Lane L = lane_of(g);
+  const int j = blockIdx.x / nfg, fg = blockIdx.x - j * nfg;
+  const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
+  const int Q = g.Q;
+  const int f = fg * g.G + L.g;
+  const int z = (synd && L.active) ? synd[(size_t)j * g.Fpad + f] : 0;
+  const bool live = L.l < g.G * Q;
+  double *rho = lds_d;   // [dc][64]
+  double nxt = 0.0;
+  for (int k = dc - 1; k >= 1; k--) {
+    const int e = p0 + k;
+    const int h = g.hval[e];
+    const double q = live ? qa[((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + L.l] : 0.0;
+    double r;
+    if (k == dc - 1) {
+      r = __shfl(q, L.base + g.mul[L.a * Q + g.hinv[e]]);   // rho[a*h] = qa[a]
+    } else {
+      double sum = 0;
+      for (int t = 0; t < Q; t++) {
+        const int s = gf_sub(g, L.a, g.mul[t * Q + h]);
+        sum += exp(__shfl(nxt, L.base + s) + __shfl(q, L.base + t));
+      }
+      r = log(sum);
+    }
+    rho[k * 64 + L.l] = r;
+    nxt = r;
+  }
+  double sig = 0.0;
+  for (int k = 0; k < dc; k++) {
+    const int e = p0 + k;
+    const int h = g.hval[e];
+    const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + L.l;
+    const double q = live ? qa[off] : 0.0;
+    const int zah = gf_sub(g, z, g.mul[L.a * Q + h]);
+    double out;
+    if (k == 0) {
+      out = 0.0;
+      if (dc > 1) out = __shfl(rho[64 + L.l], L.base + zah);
+    } else if (k == dc - 1) {
+      out = __shfl(sig, L.base + zah);
+    } else {
+      const double rn = rho[(k + 1) * 64 + L.l];
+      double sum = 0;
+      for (int t = 0; t < Q; t++) {
+        const int s = gf_sub(g, zah, t);
+        sum += exp(__shfl(sig, L.base + s) + __shfl(rn, L.base + t));
+      }
+      out = log(sum);
+    }
+    if (live) ra[off] = out;
+    double ns;
+    if (k == 0) {
+      ns = __shfl(q, L.base + g.mul[L.a * Q + g.hinv[e]]);   // sigma[a*h] = qa[a]
+    } else {
+      double sum = 0;
+      for (int t = 0; t < Q; t++) {
+        const int s = gf_sub(g, L.a, g.mul[t * Q + h]);
+        sum += exp(__shfl(sig, L.base + s) + __shfl(q, L.base + t));
+      }
+      ns = log(sum);
+    }
+    sig = ns;
+  }
+}
+
+// GFq_LDPC.c:426-457
+__global__ __launch_bounds__(256) void gfq_vn_kernel(GGraph g, int nfg, const double *__restrict__ fna,
+                                                     const double *__restrict__ ra, double *__restrict__ qa,
+                                                     uint8_t *__restrict__ xhat,
+                                                     const uint8_t *__restrict__ frozen) {
+  const Lane L = lane_of(g);
+  const long item = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (item >= (long)g.n * nfg) return;
+  const int i = (int)(item / nfg), fg = (int)(item - (long)i * nfg);
+  const int p0 = g.col_ptr[i], dv = g.col_ptr[i + 1] - p0;
+  const int Q = g.Q;
+  const bool live = L.l < g.G * Q;
+  const size_t fo = (size_t)fg * g.G * Q + L.l;
+  double logprod = live ? fna[(size_t)i * g.Fpad * Q + fo] : 0.0;
+  for (int k = 0; k < dv; k++) {
+    const int e = g.edge_of[p0 + k];
+    logprod += live ? ra[(size_t)e * g.Fpad * Q + fo] : 0.0;
+  }
+  double maxp = -9e99;
+  int arg = -1;
+  for (int t = 0; t < Q; t++) {
+    const double v = __shfl(logprod, L.base + t);
+    if (v > maxp) { maxp = v; arg = t; }
+  }
+  const int f = fg * g.G + L.g;
+  if (live && L.a == 0 && !frozen[f]) xhat[(size_t)i * g.Fpad + f] = (uint8_t)arg;
+  for (int k = 0; k < dv; k++) {
+    const int e = g.edge_of[p0 + k];
+    const size_t off = (size_t)e * g.Fpad * Q + fo;
+    const double q = logprod - (live ? ra[off] : 0.0);
+    const double ex = exp(q);
+    double sum = 0;
+    for (int t = 0; t < Q; t++) sum += __shfl(ex, L.base + t);
+    if (live) qa[off] = q - log(sum);
+  }
+}
+
+// ------------------------------------------------- syndrome + frame state
+
+// enc() (GFq_LDPC.c:299-310) of the current estimate and the distance to the
+// target syndrome: bit count for GF(2^p) (HamDist, GFq_LDPC_NTT.c:253-262),
+// symbol count otherwise.  One thread per (check, frame); frames across lanes.
+__global__ __launch_bounds__(256) void gf_synd_kernel(GGraph g, const uint8_t *__restrict__ xhat,
+                                                      const uint8_t *__restrict__ synd,
+                                                      uint8_t *__restrict__ zhat, int *__restrict__ dist,
+                                                      const uint8_t *__restrict__ frozen) {
+  const size_t total = (size_t)g.m * g.Fpad;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int f = (int)(idx % g.Fpad);
+  const int j = (int)(idx / g.Fpad);
+  if (frozen[f]) return;
+  int sum = 0;
+  for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++)
+    sum = gf_add(g, sum, g.mul[xhat[(size_t)g.col_idx[e] * g.Fpad + f] * g.Q + g.hval[e]]);
+  zhat[idx] = (uint8_t)sum;
+  const int z = synd ? synd[idx] : 0;
+  const int d = g.pow2 ? __popc((unsigned)(z ^ sum)) : (z != sum);
+  if (d) atomicAdd(&dist[f], d);
+}
+
+struct FrameState {
+  int32_t *dist, *iters, *status, *iir, *prev, *nodecr;
+  uint8_t *frozen;
+};
+
+__global__ void gf_state_init_kernel(FrameState s, int Fpad, int nframes) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= Fpad) return;
+  s.dist[f] = 0;
+  s.iters[f] = 0;
+  s.status[f] = 1;
+  s.iir[f] = 0;
+  s.prev[f] = 999999;
+  s.nodecr[f] = 0;
+  s.frozen[f] = f >= nframes;
+}
+
+// After iteration `loop` (0-based): exit test (GFq_LDPC.c:459-463) and, for the
+// WHT decoder, its non-convergence abort (GFq_LDPC_NTT.c:527-540).
+__global__ void gf_state_kernel(FrameState s, int Fpad, int loop, int wht, int32_t *remaining) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  int rem = 0;
+  if (f < Fpad && !s.frozen[f]) {
+    const int d = s.dist[f];
+    s.dist[f] = 0;
+    s.iters[f] = loop + 1;
+    bool stop = false;
+    if (d == 0) {
+      s.status[f] = 0;
+      stop = true;
+    } else if (wht) {
+      int iir = s.iir[f];
+      if (loop == 0) iir = d;
+      else iir = (int)__dadd_rn(__dadd_rn(__dmul_rn((double)iir, 0.85), __dmul_rn((double)d, 0.15)), 0.5);
+      int nd = s.nodecr[f];
+      if (s.prev[f] <= d) nd++;
+      else nd = 0;
+      if ((double)d > __dmul_rn((double)iir, 1.1) || nd > 10) stop = true;
+      s.iir[f] = iir;
+      s.nodecr[f] = nd;
+      s.prev[f] = d;
+    }
+    if (stop) s.frozen[f] = 1;
+    else rem = 1;
+  }
+  rem = __syncthreads_count(rem);
+  if (threadIdx.x == 0 && rem) atomicAdd(remaining, rem);
+}
+
+__global__ void gf_state_out_kernel(FrameState s, int nframes, int32_t *iters_out, int32_t *status_out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  if (iters_out) iters_out[f] = s.iters[f];
+  if (status_out) status_out[f] = s.status[f];
+}
+
+// ------------------------------------------------------------------ engine
+
+template <typename T, bool WHT>
+struct GfEngine : Engine {
+  ldpc_opts opts{};
+  int n = 0, m = 0, E = 0, Q = 0, rmax = 0;
+  int G = 1, Fpad_max = 0;
+  GGraph g{};
+  WTab tab{};
+  DevBuf d_row_ptr, d_col_idx, d_hval, d_hinv, d_col_ptr, d_edge_of, d_mul, d_flog, d_fexp;
+  DevBuf fna, qa, ra, xhat, zhat, synd, st_i32, st_frozen, remaining;
+  int32_t *h_remaining = nullptr;
+  int remaining_cap = 0;
+  hipEvent_t ev[4] = {};
+  FrameState fs{};
+
+  ~GfEngine() override {
+    if (h_remaining) (void)hipHostFree(h_remaining);
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  size_t llr_elems_per_frame() const override { return (size_t)n * Q; }
+
+  template <typename U>
+  int upload(DevBuf &b, const std::vector<U> &v) {
+    int rc = b.ensure(sizeof(U) * (v.size() ? v.size() : 1));
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(b.p, v.data(), sizeof(U) * v.size(), hipMemcpyHostToDevice));
+    return LDPC_OK;
+  }
+  int ensure_remaining(int slots) {
+    if (slots <= remaining_cap) return LDPC_OK;
+    if (h_remaining) (void)hipHostFree(h_remaining);
+    h_remaining = nullptr;
+    const int cap = slots < 256 ? 256 : slots;
+    HIPCHK(hipHostMalloc((void **)&h_remaining, sizeof(int32_t) * cap, hipHostMallocDefault));
+    int rc = remaining.ensure(sizeof(int32_t) * cap);
+    if (rc) return rc;
+    remaining_cap = cap;
+    return LDPC_OK;
+  }
+
+  int init(const ldpc_code &c, const ldpc_opts &o) override {
+    opts = o;
+    n = c.n; m = c.m; E = c.E(); Q = c.q; rmax = c.rmax;
+    const bool pow2 = (Q & (Q - 1)) == 0;
+    int log2q = 0;
+    while ((1 << log2q) < Q) log2q++;
+    if (Q > 64 || Q < 3 || (WHT && (!pow2 || log2q < 2))) {
+      ldpc_set_error(WHT ? "GF2P_WHT needs a GF(2^p) code with 4 <= q <= 64"
+                         : "GFQ_DIRECT needs 3 <= q <= 64");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+    if (!pow2)
+      for (int d = 2; d * d <= Q; d++)
+        if (Q % d == 0) {
+          ldpc_set_error("q is neither prime nor a power of two");
+          return LDPC_ERR_UNSUPPORTED;
+        }
+    const size_t lds = (size_t)rmax * 64 * 8;
+    if (lds > 160 * 1024) {
+      ldpc_set_error("row weight too large for the LDS-staged GF check node");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+    G = 64 / Q;
+    const int mf = o.max_frames > 0 ? o.max_frames : 1024;
+    Fpad_max = (mf + G - 1) / G * G;
+
+    std::vector<uint8_t> mul((size_t)Q * Q);
+    std::vector<int32_t> inv(Q, 0);
+    for (int a = 0; a < Q; a++)
+      for (int b = 0; b < Q; b++) {
+        const int p = ldpc_gf_mul_host(Q, a, b);
+        mul[(size_t)a * Q + b] = (uint8_t)p;
+        if (p == 1) inv[a] = b;
+      }
+    std::vector<int32_t> hinv(E);
+    for (int e = 0; e < E; e++) hinv[e] = inv[c.hval[e]];
+    int rc;
+    if ((rc = upload(d_row_ptr, c.row_ptr))) return rc;
+    if ((rc = upload(d_col_idx, c.col_idx))) return rc;
+    if ((rc = upload(d_hval, c.hval))) return rc;
+    if ((rc = upload(d_hinv, hinv))) return rc;
+    if ((rc = upload(d_col_ptr, c.col_ptr))) return rc;
+    if ((rc = upload(d_edge_of, c.edge_of))) return rc;
+    if ((rc = upload(d_mul, mul))) return rc;
+    g.row_ptr = d_row_ptr.as<int32_t>();
+    g.col_idx = d_col_idx.as<int32_t>();
+    g.hval = d_hval.as<int32_t>();
+    g.hinv = d_hinv.as<int32_t>();
+    g.col_ptr = d_col_ptr.as<int32_t>();
+    g.edge_of = d_edge_of.as<int32_t>();
+    g.mul = d_mul.as<uint8_t>();
+    g.n = n; g.m = m; g.E = E; g.Q = Q; g.log2q = log2q; g.pow2 = pow2; g.G = G; g.Fpad = Fpad_max;
+    if (WHT) {
+      std::vector<int32_t> fl;
+      std::vector<uint32_t> fe;
+      ldpc_build_wht_tables(fl, fe);
+      if ((rc = upload(d_flog, fl))) return rc;
+      if ((rc = upload(d_fexp, fe))) return rc;
+      tab.flog = d_flog.as<int32_t>();
+      tab.fexp = d_fexp.as<uint32_t>() + W_LEVELS;
+    }
+    const size_t per = (size_t)Fpad_max * Q * sizeof(T);
+    if ((rc = fna.ensure(per * n))) return rc;
+    if ((rc = qa.ensure(per * E))) return rc;
+    if ((rc = ra.ensure(per * E))) return rc;
+    if ((rc = xhat.ensure((size_t)Fpad_max * n))) return rc;
+    if ((rc = zhat.ensure((size_t)Fpad_max * m))) return rc;
+    if ((rc = synd.ensure((size_t)Fpad_max * m))) return rc;
+    if ((rc = st_i32.ensure((size_t)Fpad_max * 6 * sizeof(int32_t)))) return rc;
+    if ((rc = st_frozen.ensure((size_t)Fpad_max))) return rc;
+    if ((rc = ensure_remaining(256))) return rc;
+    for (auto &e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (lds > 64 * 1024) {
+      if (WHT)
+        HIPCHK(hipFuncSetAttribute((const void *)gf2p_cn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+      else
+        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    }
+    return LDPC_OK;
+  }
+
+  static unsigned blocks_for(size_t items, int per_block) {
+    size_t b = (items + per_block - 1) / per_block;
+    if (b > 65536) b = 65536;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+  }
+
+  int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+             int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+             hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
+    if (llr_out) {
+      ldpc_set_error("llr_out is not available for the non-binary algorithms");
+      return LDPC_ERR_ARG;
+    }
+    const int Fpad = (nframes + G - 1) / G * G;
+    if (Fpad > Fpad_max || !llr || max_iter < 0 || max_iter > 65000) {
+      ldpc_set_error("nframes/max_iter out of range for this decoder");
+      return LDPC_ERR_ARG;
+    }
+    int rc;
+    if ((rc = ensure_remaining(max_iter + 2))) return rc;
+    GGraph gg = g;
+    gg.Fpad = Fpad;
+    const int nfg = Fpad / G;
+    fs.dist = st_i32.as<int32_t>();
+    fs.iters = fs.dist + Fpad_max;
+    fs.status = fs.iters + Fpad_max;
+    fs.iir = fs.status + Fpad_max;
+    fs.prev = fs.iir + Fpad_max;
+    fs.nodecr = fs.prev + Fpad_max;
+    fs.frozen = st_frozen.as<uint8_t>();
+
+    hipLaunchKernelGGL(gf_state_init_kernel, dim3((Fpad + 255) / 256), dim3(256), 0, st, fs, Fpad, nframes);
+    LAUNCHCHK("gf_state_init_kernel");
+    HIPCHK(hipMemsetAsync(remaining.p, 0, sizeof(int32_t) * (max_iter + 2), st));
+    HIPCHK(hipMemsetAsync(xhat.p, 0, (size_t)Fpad * n, st));
+    HIPCHK(hipMemsetAsync(zhat.p, 0, (size_t)Fpad * m, st));
+
+    const unsigned gi = blocks_for((size_t)n * Fpad * Q, 256);
+    if (WHT) {
+      if (dt == LDPC_DT_I32)
+        hipLaunchKernelGGL((gf_ingest_kernel<int, T, WHT>), dim3(gi), dim3(256), 0, st, (const int *)llr,
+                           nframes, gg, fna.as<T>());
+      else if (dt == LDPC_DT_F64)
+        hipLaunchKernelGGL((gf_ingest_kernel<double, T, WHT>), dim3(gi), dim3(256), 0, st, (const double *)llr,
+                           nframes, gg, fna.as<T>());
+      else if (dt == LDPC_DT_F32)
+        hipLaunchKernelGGL((gf_ingest_kernel<float, T, WHT>), dim3(gi), dim3(256), 0, st, (const float *)llr,
+                           nframes, gg, fna.as<T>());
+      else { ldpc_set_error("GF2P_WHT takes I32 (raw Q.14), F64 or F32 log2 values"); return LDPC_ERR_ARG; }
+    } else {
+      if (dt == LDPC_DT_F64)
+        hipLaunchKernelGGL((gf_ingest_kernel<double, T, WHT>), dim3(gi), dim3(256), 0, st, (const double *)llr,
+                           nframes, gg, fna.as<T>());
+      else if (dt == LDPC_DT_F32)
+        hipLaunchKernelGGL((gf_ingest_kernel<float, T, WHT>), dim3(gi), dim3(256), 0, st, (const float *)llr,
+                           nframes, gg, fna.as<T>());
+      else { ldpc_set_error("GFQ_DIRECT takes F64 or F32 natural-log values"); return LDPC_ERR_ARG; }
+    }
+    LAUNCHCHK("gf_ingest_kernel");
+    const uint8_t *sy = nullptr;
+    if (sy_in) {
+      hipLaunchKernelGGL(gf_sym_in_kernel, dim3(blocks_for((size_t)m * Fpad, 256)), dim3(256), 0, st, sy_in,
+                         nframes, m, Fpad, synd.as<uint8_t>());
+      LAUNCHCHK("gf_sym_in_kernel");
+      sy = synd.as<uint8_t>();
+    }
+    hipLaunchKernelGGL((gf_init_kernel<T>), dim3(blocks_for((size_t)E * Fpad * Q, 256)), dim3(256), 0, st, gg,
+                       fna.as<T>(), qa.as<T>());
+    LAUNCHCHK("gf_init_kernel");
+
+    const size_t lds = (size_t)rmax * 64 * 8;
+    const unsigned vn_blocks = (unsigned)(((size_t)n * nfg + 3) / 4);
+    int executed = 0;
+    const bool early = opts.early_exit != 0;
+    for (int t = 0; t < max_iter; t++) {
+      prof_begin(K_CN, st);
+      if constexpr (WHT)
+        hipLaunchKernelGGL(gf2p_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, tab, nfg,
+                           qa.as<int>(), ra.as<int>(), sy);
+      else
+        hipLaunchKernelGGL(gfq_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg,
+                           qa.as<double>(), ra.as<double>(), sy);
+      LAUNCHCHK("gf cn kernel");
+      prof_end(st);
+      prof_begin(K_VN, st);
+      if constexpr (WHT)
+        hipLaunchKernelGGL(gf2p_vn_kernel, dim3(vn_blocks), dim3(256), 0, st, gg, tab, nfg, fna.as<int>(),
+                           ra.as<int>(), qa.as<int>(), xhat.as<uint8_t>(), fs.frozen);
+      else
+        hipLaunchKernelGGL(gfq_vn_kernel, dim3(vn_blocks), dim3(256), 0, st, gg, nfg, fna.as<double>(),
+                           ra.as<double>(), qa.as<double>(), xhat.as<uint8_t>(), fs.frozen);
+      LAUNCHCHK("gf vn kernel");
+      prof_end(st);
+      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)(((size_t)m * Fpad + 255) / 256)), dim3(256), 0, st, gg,
+                         xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen);
+      LAUNCHCHK("gf_synd_kernel");
+      hipLaunchKernelGGL(gf_state_kernel, dim3((Fpad + 255) / 256), dim3(256), 0, st, fs, Fpad, t, WHT ? 1 : 0,
+                         remaining.as<int32_t>() + t);
+      LAUNCHCHK("gf_state_kernel");
+      executed = t + 1;
+      if (early) {
+        HIPCHK(hipMemcpyAsync(h_remaining + t, remaining.as<int32_t>() + t, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ev[t % 4], st));
+        if (t >= 1) {
+          HIPCHK(hipEventSynchronize(ev[(t - 1) % 4]));
+          if (h_remaining[t - 1] == 0) break;
+        }
+      }
+    }
+    last_iterations = executed;
+    if (bits) {
+      hipLaunchKernelGGL(gf_sym_out_kernel, dim3(blocks_for((size_t)n * nframes, 256)), dim3(256), 0, st,
+                         xhat.as<uint8_t>(), nframes, n, Fpad, bits);
+      LAUNCHCHK("gf_sym_out_kernel");
+    }
+    if (sout_out) {
+      hipLaunchKernelGGL(gf_sym_out_kernel, dim3(blocks_for((size_t)m * nframes, 256)), dim3(256), 0, st,
+                         zhat.as<uint8_t>(), nframes, m, Fpad, sout_out);
+      LAUNCHCHK("gf_sym_out_kernel(synd)");
+    }
+    if (iters_out || status) {
+      hipLaunchKernelGGL(gf_state_out_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, fs, nframes,
+                         iters_out, status);
+      LAUNCHCHK("gf_state_out_kernel");
+    }
+    return LDPC_OK;
+  }
+};
+
+}  // namespace gf
+
 Engine *ldpc_make_gf_engine(int alg, const ldpc_code &c) {
-  (void)alg;
-  (void)c;
+  if (c.q <= 2) return nullptr;
+  if (alg == LDPC_ALG_GF2P_WHT) return new gf::GfEngine<int, true>;
+  if (alg == LDPC_ALG_GFQ_DIRECT) return new gf::GfEngine<double, false>;
   return nullptr;
 }

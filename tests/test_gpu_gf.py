@@ -1,0 +1,125 @@
+"""GPU parity of the non-binary decoders (through the C-ABI) against the oracle and
+against the committed outputs of the compiled reference GFq_LDPC_NTT.c."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, code_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("q,fname", [(4, "q4.sp.9000.6000.4500.1"), (8, "q8.sp.6000.4000.3000.1")])
+def test_gf2p_wht_golden_reference_vectors(hip, q, fname):
+    """main():681-695 experiments of the reference program (seeds 1..3 + one
+    non-convergent frame): decoded symbols, syndrome and verdict, bit-exact."""
+    g = np.load(os.path.join(GOLDEN, f"ref_ntt_q{q}.npz"))
+    code = hip.Code.from_alist(code_path(fname))
+    assert code.q == q
+    dec = hip.Decoder(code, hip.ALG.GF2P_WHT, max_frames=16)
+    out = dec.decode(g["logfna"].astype(np.int32), g["s"], int(g["maxit"]))
+    assert np.array_equal(out["status"] != 0, g["rc"] != 0)
+    assert np.array_equal(out["bits"], g["xhat"])
+    assert np.array_equal(out["synd"], g["zhat"])
+    conv = g["rc"] == 0
+    assert np.array_equal(out["bits"][conv], g["x"][conv])
+
+
+def _wht_frames(oracle, oc, q, F, p, seed):
+    """BSC on the symbol bits, log2-domain Q.14 priors (GFq_LDPC_NTT.c:278-315)."""
+    rng = np.random.default_rng(seed)
+    log2q = int(np.log2(q))
+    x = rng.integers(0, q, size=(F, oc.n)).astype(np.int32)
+    x[: F // 3] = 0
+    s = np.stack([oracle.gf_enc(oc, q, x[f]) for f in range(F)])
+    p = np.where(np.arange(F) % 2 == 0, p, 1.75 * p)[:, None]      # every other frame is harder
+    err = np.zeros((F, oc.n), np.int32)
+    for b in range(log2q):
+        err |= (rng.random((F, oc.n)) < p).astype(np.int32) << b
+    y = x ^ err
+    a = np.arange(q)
+    diff = (y[:, :, None] ^ a[None, None, :])
+    nb = np.zeros_like(diff)
+    for b in range(log2q):
+        nb += (diff >> b) & 1
+    logp = nb * np.log2(p)[:, :, None] + (log2q - nb) * np.log2(1 - p)[:, :, None]
+    return x, s, oracle.wht_float2fix(logp), logp
+
+
+@pytest.mark.parametrize("q,fname,F,p,it", [(4, "q4.sp.9000.6000.4500.1", 21, 0.085, 30),
+                                            (8, "q8.sp.6000.4000.3000.1", 19, 0.07, 30)])
+def test_gf2p_wht_vs_oracle(hip, oracle, q, fname, F, p, it):
+    oc = oracle.load(code_path(fname))
+    x, s, logfna, logp = _wht_frames(oracle, oc, q, F, p, 21)
+    log2q = int(np.log2(q))
+    ref = [oracle.dec_gf2p_wht(oc, log2q, logfna[f], s[f], it) for f in range(F)]
+    assert all(r["rc"] in (0, -1) for r in ref)
+    code = hip.Code.from_alist(code_path(fname))
+    dec = hip.Decoder(code, hip.ALG.GF2P_WHT, max_frames=16)        # F > max_frames: two passes
+    for inp in (logfna.astype(np.int32), logp.astype(np.float64)):
+        out = dec.decode(inp, s.astype(np.uint8), it)
+        assert np.array_equal(out["status"], np.array([0 if r["rc"] == 0 else 1 for r in ref]))
+        assert np.array_equal(out["iters"], np.array([r["iters"] for r in ref]))
+        assert np.array_equal(out["bits"], np.stack([r["x"] for r in ref]))
+        assert np.array_equal(out["synd"], np.stack([r["z"] for r in ref]))
+    assert any(r["rc"] == 0 for r in ref)
+
+
+def _conf_matrix(q, perr):
+    """Symmetric +-1 confusion matrix in the shape test_mex_NB_p.m:35-47 builds
+    ([rec][sent], one read)."""
+    c = np.zeros((q, q))
+    for sent in range(q):
+        c[sent, sent] = 1 - perr
+        c[(sent + 1) % q, sent] += perr / 2
+        c[(sent - 1) % q, sent] += perr / 2
+    return c
+
+
+@pytest.mark.parametrize("fname,q,F,perr,it", [("peg_4376_4_0.9_NB.txt", 13, 6, 0.012, 12),
+                                               ("q4.sp.9000.6000.4500.1", 4, 5, 0.12, 12)])
+def test_gfq_direct_vs_oracle(hip, oracle, fname, q, F, perr, it):
+    """binary64 log-domain decoder: libm differs between host and device, so parity is on
+    decoded symbols / iterations / verdict (identical on these inputs)."""
+    oc = oracle.load(code_path(fname))
+    rng = np.random.default_rng(31)
+    conf = _conf_matrix(q, perr)
+    x = rng.integers(0, q, size=(F, oc.n)).astype(np.int32)
+    x[0] = 0
+    s = np.stack([oracle.gf_enc(oc, q, x[f]) for f in range(F)])
+    u = rng.random((F, oc.n))
+    pe = np.where(np.arange(F) % 3 == 2, 5 * perr, perr)[:, None]  # every third frame is hopeless
+    y = np.where(u < pe / 2, (x + 1) % q, np.where(u < pe, (x - 1) % q, x)).astype(np.int32)
+    logfna = np.stack([oracle.gf_assign_llr(q, 1, conf, y[f]) for f in range(F)])      # [F][q][n]
+    ref = [oracle.dec_gfq_direct(oc, q, logfna[f], s[f], it) for f in range(F)]
+    code = hip.Code.from_alist(code_path(fname))
+    dec = hip.Decoder(code, hip.ALG.GFQ_DIRECT, max_frames=4)
+    out = dec.decode(np.ascontiguousarray(logfna.transpose(0, 2, 1)), s.astype(np.uint8), it)
+    assert np.array_equal(out["status"], np.array([r["rc"] for r in ref]))
+    assert np.array_equal(out["iters"], np.array([r["iters"] for r in ref]))
+    assert np.array_equal(out["bits"], np.stack([r["x"] for r in ref]))
+    assert np.array_equal(out["synd"], np.stack([r["z"] for r in ref]))
+    assert any(r["rc"] == 0 for r in ref) and any(r["rc"] != 0 for r in ref)
+
+
+def test_gfq_ldpc_harness(hip):
+    """GFq_LDPC() (GFq_LDPC.c:540-655) through the reference-shaped entry point."""
+    import ctypes as C
+    L = hip.load_library()
+    L.ldpc_set_seed(1234)
+    q = 13
+    conf = np.ascontiguousarray(_conf_matrix(q, 0.01) * 3.0)      # un-normalised on purpose
+    err = (C.c_double * 2)()
+    rc = L.GFq_LDPC(code_path("peg_4376_4_0.9_NB.txt").encode(), 15, 6, 0, 1, 0,
+                    conf.ctypes.data_as(C.POINTER(C.c_double)), err)
+    assert rc == 0, L.ldpc_last_error()
+    assert err[0] == 0 and err[1] == 0
+    assert np.allclose(conf.sum(axis=0), 1.0)                    # normalised in place, :548-558
+    conf2 = np.ascontiguousarray(_conf_matrix(q, 0.5))
+    rc = L.GFq_LDPC(code_path("peg_4376_4_0.9_NB.txt").encode(), 3, 4, 0, 1, 0,
+                    conf2.ctypes.data_as(C.POINTER(C.c_double)), err)
+    assert rc == 0 and err[0] == 4
+    rc = L.GFq_LDPC(code_path("peg_4376_4_0.9_NB.txt").encode(), 3, 4, 0, 1, 1,
+                    conf2.ctypes.data_as(C.POINTER(C.c_double)), err)
+    assert rc == -6
