@@ -568,6 +568,40 @@ __global__ void mark_kernel(int nslab, int V, int nframes, int it, int ignore, u
   }
 }
 
+// ------------------------------------------------------------ message trace
+//
+// Single-frame read-outs for the Verilog trace of test_code_min_sum_B_fixed.c.
+// trace_v2c: what :250-256 prints, the UNSATURATED sum - qin[v][slot] of every
+// edge, computed from the c2v messages currently in `msg` (first != 0: they are
+// all zero, memset at :196).  trace_msg: the messages as stored (:293).
+template <typename T>
+__global__ void trace_v2c_kernel(Graph g, const typename MT<T>::vec *__restrict__ q0,
+                                 const typename MT<T>::vec *__restrict__ msg, int frame, int first,
+                                 int32_t *__restrict__ out) {
+  constexpr int V = MT<T>::V;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.n) return;
+  const int b = frame / (64 * V), lane = (frame % (64 * V)) / V, v = frame % V;
+  const int p0 = g.col_ptr[i], dv = g.col_ptr[i + 1] - p0;
+  int sum = (int)q0[((size_t)b * g.n + i) * 64 + lane][v];
+  if (!first)
+    for (int k = 0; k < dv; k++) sum += (int)msg[((size_t)b * g.E + g.edge_of[p0 + k]) * 64 + lane][v];
+  for (int k = 0; k < dv; k++) {
+    const int e = g.edge_of[p0 + k];
+    out[e] = first ? sum : sum - (int)msg[((size_t)b * g.E + e) * 64 + lane][v];
+  }
+}
+
+template <typename T>
+__global__ void trace_msg_kernel(Graph g, const typename MT<T>::vec *__restrict__ msg, int frame,
+                                 int32_t *__restrict__ out) {
+  constexpr int V = MT<T>::V;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.E) return;
+  const int b = frame / (64 * V), lane = (frame % (64 * V)) / V, v = frame % V;
+  out[e] = (int)msg[((size_t)b * g.E + e) * 64 + lane][v];
+}
+
 // ---------------------------------------------------------- ingest / egress
 
 // float_to_fix() (test_code_min_sum_B_fixed.c:43-53) to raw Q8.8

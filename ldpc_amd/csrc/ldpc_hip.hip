@@ -153,7 +153,8 @@ struct BinaryEngine : Engine {
   int num_cu = 256;
   int cn_variant = 0;
   int vn_bucket = 0;
-  DevBuf g_row_ptr, g_col_idx, g_col_ptr, g_edge_of;
+  DevBuf g_row_ptr, g_col_idx, g_col_ptr, g_edge_of, trace_buf;
+  std::vector<int32_t> h_row_ptr, h_col_idx, h_col_ptr, h_edge_of;   // host copy (trace ordering)
   DevBuf q0, msg, post, hard, synd, sout, fail, done, iters, remaining, tab_lt, tab_g;
   int32_t *h_remaining = nullptr;
   int remaining_cap = 0;
@@ -191,6 +192,7 @@ struct BinaryEngine : Engine {
   int init(const ldpc_code &c, const ldpc_opts &o) override {
     opts = o;
     n = c.n; m = c.m; E = c.E(); cmax = c.cmax; rmax = c.rmax;
+    h_row_ptr = c.row_ptr; h_col_idx = c.col_idx; h_col_ptr = c.col_ptr; h_edge_of = c.edge_of;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, o.device));
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -365,27 +367,8 @@ struct BinaryEngine : Engine {
     HIPCHK(hipMemsetAsync(hard.p, 0, (size_t)nslab * 64 * n, st));
     if (opts.want_llr) HIPCHK(hipMemsetAsync(post.p, 0, (size_t)nslab * 64 * n * sizeof(vec), st));
 
-    switch (dt) {
-      case LDPC_DT_F64: rc = launch_ingest<double>(llr, nframes, nslab, st); break;
-      case LDPC_DT_F32: rc = launch_ingest<float>(llr, nframes, nslab, st); break;
-      case LDPC_DT_I16:
-        if (ALG != ALG_MSQ) { ldpc_set_error("I16 input is for MINSUM_Q88"); return LDPC_ERR_ARG; }
-        rc = launch_ingest<short>(llr, nframes, nslab, st);
-        break;
-      case LDPC_DT_I32:
-        if (ALG != ALG_TAB && ALG != ALG_MSQ) { ldpc_set_error("I32 input is for SPA_TABLE_Q14 / MINSUM_Q88"); return LDPC_ERR_ARG; }
-        rc = launch_ingest<int>(llr, nframes, nslab, st);
-        break;
-      default: ldpc_set_error("bad llr_dtype"); return LDPC_ERR_ARG;
-    }
-    if (rc) return rc;
     const uint8_t *sy = nullptr;
-    if (sy_in) {
-      hipLaunchKernelGGL((ingest_synd_kernel<V>), dim3((m + 63) / 64, nslab), dim3(256), 0, st, sy_in,
-                         nframes, m, synd.as<uint8_t>());
-      LAUNCHCHK("ingest_synd_kernel");
-      sy = synd.as<uint8_t>();
-    }
+    if ((rc = ingest_all(nframes, nslab, llr, dt, sy_in, &sy, st))) return rc;
 
     // iteration 1's variable pass: c2v = 0, also emits sign(q0) as "iteration 0" decisions
     prof_begin(K_VN, st);
@@ -431,6 +414,11 @@ struct BinaryEngine : Engine {
     }
     last_iterations = executed;
 
+    return emit_outputs(nframes, nslab, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+  }
+
+  int emit_outputs(int nframes, int nslab, int max_iter, uint8_t *bits, int32_t *iters_out,
+                   uint8_t *sout_out, int32_t *status, float *llr_out, hipStream_t st) {
     if (bits) {
       hipLaunchKernelGGL((egress_bits_kernel<V>), dim3((n + 63) / 64, nslab), dim3(256), 0, st,
                          hard.as<uint8_t>(), nframes, n, bits);
@@ -452,6 +440,135 @@ struct BinaryEngine : Engine {
       LAUNCHCHK("egress_post_kernel");
     }
     return LDPC_OK;
+  }
+
+  int ingest_all(int nframes, int nslab, const void *llr, int dt, const uint8_t *sy_in, const uint8_t **sy,
+                 hipStream_t st) {
+    int rc;
+    switch (dt) {
+      case LDPC_DT_F64: rc = launch_ingest<double>(llr, nframes, nslab, st); break;
+      case LDPC_DT_F32: rc = launch_ingest<float>(llr, nframes, nslab, st); break;
+      case LDPC_DT_I16:
+        if (ALG != ALG_MSQ) { ldpc_set_error("I16 input is for MINSUM_Q88"); return LDPC_ERR_ARG; }
+        rc = launch_ingest<short>(llr, nframes, nslab, st);
+        break;
+      case LDPC_DT_I32:
+        if (ALG != ALG_TAB && ALG != ALG_MSQ) { ldpc_set_error("I32 input is for SPA_TABLE_Q14 / MINSUM_Q88"); return LDPC_ERR_ARG; }
+        rc = launch_ingest<int>(llr, nframes, nslab, st);
+        break;
+      default: ldpc_set_error("bad llr_dtype"); return LDPC_ERR_ARG;
+    }
+    if (rc) return rc;
+    *sy = nullptr;
+    if (sy_in) {
+      hipLaunchKernelGGL((ingest_synd_kernel<V>), dim3((m + 63) / 64, nslab), dim3(256), 0, st, sy_in,
+                         nframes, m, synd.as<uint8_t>());
+      LAUNCHCHK("ingest_synd_kernel");
+      *sy = synd.as<uint8_t>();
+    }
+    return LDPC_OK;
+  }
+
+  int launch_synd(int nslab, const uint8_t *sy, hipStream_t st) {
+    const int wps = balanced_wps(nslab, (long)num_cu * 16);
+    const long waves = (long)wps * nslab;
+    hipLaunchKernelGGL(synd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, g, nslab,
+                       hard.as<uint8_t>(), sy, sout.as<uint8_t>(), fail.as<uint32_t>());
+    LAUNCHCHK("synd_kernel");
+    return LDPC_OK;
+  }
+
+  // Single frame with the reference's Verilog message trace (_fixed.c:205, :245-260,
+  // :288-296).  The passes are the batch kernels; after each one the frame's messages
+  // are read back and the host only orders and prints them.
+  int decode_traced(const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+                    int32_t *iters_out, uint8_t *sout_out, int32_t *status, FILE *fp,
+                    int circ) override {
+    if constexpr (ALG != ALG_MSQ) {
+      return Engine::decode_traced(llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, fp, circ);
+    } else {
+      if (!llr || max_iter < 0 || max_iter > 65000 || circ <= 0) return LDPC_ERR_ARG;
+      // the c2v dump prints row_weight[circ*k] entries of every row of block k (:290): on a
+      // code where a row of the block is lighter the reference reads unset pointers
+      for (int k = 0; k < m / circ; k++) {
+        const int w0 = h_row_ptr[circ * k + 1] - h_row_ptr[circ * k];
+        for (int j = 0; j < circ; j++)
+          if (h_row_ptr[circ * k + j + 1] - h_row_ptr[circ * k + j] < w0) {
+            ldpc_set_error("trace: rows of one circulant block differ in weight (the reference's dump is "
+                           "for quasi-cyclic codes only)");
+            return LDPC_ERR_UNSUPPORTED;
+          }
+      }
+      hipStream_t st = nullptr;
+      int rc;
+      if ((rc = ensure_remaining(max_iter + 3))) return rc;
+      if ((rc = trace_buf.ensure(sizeof(int32_t) * (size_t)E))) return rc;
+      std::vector<int32_t> hbuf(E), row_of(E), shown(n);
+      for (int j = 0; j < m; j++)
+        for (int e = h_row_ptr[j]; e < h_row_ptr[j + 1]; e++) row_of[e] = j;
+      const int nslab = 1, nframes = 1;
+      hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, st, nslab, V, nframes, fail.as<uint32_t>(),
+                         done.as<uint8_t>(), iters.as<int32_t>());
+      LAUNCHCHK("init_state_kernel");
+      HIPCHK(hipMemsetAsync(remaining.p, 0, sizeof(int32_t) * (max_iter + 3), st));
+      HIPCHK(hipMemsetAsync(hard.p, 0, (size_t)64 * n, st));
+      if (opts.want_llr) HIPCHK(hipMemsetAsync(post.p, 0, (size_t)64 * n * sizeof(vec), st));
+      const uint8_t *sy = nullptr;
+      if ((rc = ingest_all(nframes, nslab, llr, dt, sy_in, &sy, st))) return rc;
+      auto converged_after = [&](int it, bool *yes) -> int {
+        int r;
+        if ((r = launch_synd(nslab, sy, st))) return r;
+        if ((r = launch_mark(nslab, nframes, it, 0, it, st))) return r;
+        HIPCHK(hipMemcpyAsync(h_remaining + it, remaining.as<int32_t>() + it, sizeof(int32_t),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *yes = h_remaining[it] == 0;
+        return LDPC_OK;
+      };
+      bool ok = false;
+      if ((rc = launch_vn<true, true>(nslab, st))) return rc;       // hard(0) = (q0 < 0)
+      if ((rc = converged_after(0, &ok))) return rc;
+      if (ok) {
+        fprintf(fp, "already cw\n");                               // :205
+      } else {
+        for (int t = 1; t <= max_iter && !ok; t++) {
+          hipLaunchKernelGGL((trace_v2c_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, g, q0.as<vec>(),
+                             msg.as<vec>(), 0, t == 1 ? 1 : 0, trace_buf.as<int32_t>());
+          LAUNCHCHK("trace_v2c_kernel");
+          if (t > 1 && (rc = launch_vn<false, true>(nslab, st))) return rc;
+          HIPCHK(hipMemcpyAsync(hbuf.data(), trace_buf.p, sizeof(int32_t) * E, hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          std::fill(shown.begin(), shown.end(), 0);
+          for (int j = 0; j < circ; j++)                             // :245-260
+            for (int i = 0; i < m / circ; i++)
+              for (int k = 0; k < n / circ; k++) {
+                const int v = circ * k + j;
+                bool hit = false;
+                for (int l = h_col_ptr[v]; l < h_col_ptr[v + 1] && !hit; l++) {
+                  const int r = row_of[h_edge_of[l]];
+                  hit = r >= circ * i && r <= circ * (i + 1) - 1;
+                }
+                if (hit) fprintf(fp, "%08x\n", (unsigned)hbuf[h_edge_of[h_col_ptr[v] + shown[v]++]]);
+              }
+          if ((rc = launch_cn(nslab, sy, st))) return rc;
+          if ((rc = launch_mark(nslab, nframes, 0, 1, max_iter + 2, st))) return rc;   // drop its syndrome test
+          hipLaunchKernelGGL((trace_msg_kernel<T>), dim3((E + 255) / 256), dim3(256), 0, st, g, msg.as<vec>(), 0,
+                             trace_buf.as<int32_t>());
+          LAUNCHCHK("trace_msg_kernel");
+          HIPCHK(hipMemcpyAsync(hbuf.data(), trace_buf.p, sizeof(int32_t) * E, hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          for (int j = 0; j < circ; j++)                             // :288-296
+            for (int k = 0; k < m / circ; k++) {
+              const int w0 = h_row_ptr[circ * k + 1] - h_row_ptr[circ * k];
+              for (int i = 0; i < w0; i++) fprintf(fp, "%08x\n", (unsigned)hbuf[h_row_ptr[circ * k + j] + i]);
+            }
+          if ((rc = launch_vn<false, false>(nslab, st))) return rc;   // hard(t)
+          if ((rc = converged_after(t, &ok))) return rc;
+          last_iterations = t;
+        }
+      }
+      return emit_outputs(nframes, nslab, max_iter, bits, iters_out, sout_out, status, nullptr, st);
+    }
   }
 };
 

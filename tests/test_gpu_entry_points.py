@@ -1,0 +1,144 @@
+"""GPU: the reference-shaped entry points and the Verilog trace, through the C-ABI."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, code_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_verilog_trace_kat_from_gpu(hip, tmp_path):
+    """Verilog_LDPC_decoder_tester.m: test_code_min_sum_B_fixed('Frolov_1024_0.5.txt', 30, ...,
+    'verilog.txt') -- every v2c / c2v message of every iteration, read back from the GPU,
+    byte-identical to the reference's stored verilog.txt."""
+    L = hip.load_library()
+    kat = np.load(os.path.join(GOLDEN, "frolov_kat.npz"))
+    want = gzip.open(os.path.join(GOLDEN, "verilog_success.txt.gz"), "rb").read()
+    y = kat["y_2048_success"].astype(np.int32)
+    n, m = 2048, 1024
+    x = np.zeros(n, np.int32)
+    s = np.zeros(m, np.int32)
+    q0 = np.where(y == 0, 11 / 256, -11 / 256).astype(np.float64)
+    err = np.zeros(2)
+    out = str(tmp_path / "verilog.txt")
+    rc = L.test_code_min_sum_B_fixed(code_path("Frolov_1024_0.5.txt").encode(), 30, _ip(x), _ip(s), _ip(y),
+                                     _dp(q0), _dp(err), out.encode())
+    assert rc == 0, L.ldpc_last_error()
+    assert err.tolist() == [0.0, 0.0]
+    assert open(out, "rb").read() == want
+    # without a trace file: same verdict through the batch path
+    rc = L.test_code_min_sum_B_fixed(code_path("Frolov_1024_0.5.txt").encode(), 30, _ip(x), _ip(s), _ip(y),
+                                     _dp(q0), _dp(err), None)
+    assert rc == 0 and err.tolist() == [0.0, 0.0]
+
+
+def test_verilog_trace_nonconvergent_vs_oracle(hip, oracle, tmp_path):
+    kat = np.load(os.path.join(GOLDEN, "frolov_kat.npz"))
+    y = kat["y_2048"].astype(np.int32)
+    q0 = np.where(y == 0, 11 / 256, -11 / 256).astype(np.float64)
+    oc = oracle.load(code_path("Frolov_1024_0.5.txt"))
+    t_ref = str(tmp_path / "ref.txt")
+    r = oracle.dec_minsum_fixed(oc, q0, np.zeros(oc.m, np.int32), 30, t_ref, 128)
+    code = hip.Code.from_alist(code_path("Frolov_1024_0.5.txt"))
+    dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=64)
+    t_gpu = str(tmp_path / "gpu.txt")
+    out = dec.decode_trace_q88(q0, np.zeros(oc.m, np.uint8), 30, t_gpu)
+    assert out["status"] == r["rc"] == 1 and out["iters"] == r["iters"] == 30
+    assert np.array_equal(out["bits"], r["bits"]) and int(out["bits"].sum()) == 107
+    a, b = open(t_gpu, "rb").read(), open(t_ref, "rb").read()
+    assert len(b.splitlines()) == 437760 and a == b
+    # "already cw" (:205): a word that satisfies the syndrome before any iteration
+    out = dec.decode_trace_q88(np.full(oc.n, 11 / 256), None, 30, t_gpu)
+    assert out["status"] == 0 and out["iters"] == 0 and open(t_gpu).read() == "already cw\n"
+    # a code whose rows inside a 128-block differ in weight: refused, as documented
+    peg = hip.Code.from_alist(code_path("peg_16000_3_0.9.txt"))
+    d2 = hip.Decoder(peg, hip.ALG.MINSUM_Q88, max_frames=64)
+    with pytest.raises(hip.LdpcError) as e:
+        d2.decode_trace_q88(np.full(peg.n, 1.0), None, 3, t_gpu)
+    assert e.value.code == -6
+
+
+@pytest.mark.parametrize("entry,alg_fn", [("test_code_min_sum_B", "dec_minsum"), ("test_code_B_float", "dec_spa")])
+def test_single_frame_entry_points(hip, oracle, entry, alg_fn):
+    L = hip.load_library()
+    path = code_path("204.33.484.txt")
+    oc = oracle.load(path)
+    rng = np.random.default_rng(5)
+    fn = getattr(L, entry)
+    seen = set()
+    for trial in range(12):
+        p = [0.02, 0.06, 0.11][trial % 3]
+        x = rng.integers(0, 2, oc.n).astype(np.int32)
+        s = oracle.enc(oc, x)
+        y = (x ^ (rng.random(oc.n) < p)).astype(np.int32)
+        q0 = ((1 - 2 * y) * np.log((1 - p) / p)).astype(np.float64)
+        err = np.zeros(2)
+        assert fn(path.encode(), 25, _ip(x), _ip(s), _ip(y), _dp(q0), _dp(err)) == 0
+        r = getattr(oracle, alg_fn)(oc, q0, s, 25)
+        want = [1.0, 0.0] if r["rc"] else [0.0, float(not np.array_equal(r["bits"], x))]
+        assert err.tolist() == want
+        seen.add(tuple(want))
+    assert len(seen) >= 2
+
+
+def test_monte_carlo_entry_points(hip):
+    """*_cw_noise_gen and test_code_B: Monte Carlo over the library's own stream, so the
+    check is statistical, as for the reference (srand(time(NULL)))."""
+    L = hip.load_library()
+    L.ldpc_set_seed(99)
+    err = np.zeros(2)
+    path = code_path("1057.244.3.txt").encode()
+    for fn in (L.test_code_min_sum_B_cw_noise_gen, L.test_code_min_sum_B_fixed_cw_noise_gen,
+               L.test_code_B_float_cw_noise_gen):
+        assert fn(path, 30, 300, 0.002, _dp(err)) == 0, L.ldpc_last_error()
+        assert err[0] <= 3 and err[1] == 0, (fn.__name__, err)
+        assert fn(path, 5, 200, 0.12, _dp(err)) == 0
+        assert err[0] >= 195, (fn.__name__, err)
+    assert L.test_code_B(30, 200, 0.004, path, _dp(err)) == 0
+    assert err[0] <= 2 and err[1] == 0
+    assert L.test_code_B(5, 100, 0.12, path, _dp(err)) == 0
+    assert err[0] >= 95
+    # reproducible under a fixed seed
+    L.ldpc_set_seed(7)
+    a = np.zeros(2)
+    L.test_code_min_sum_B_cw_noise_gen(path, 15, 400, 0.007, _dp(a))
+    L.ldpc_set_seed(7)
+    b = np.zeros(2)
+    L.test_code_min_sum_B_cw_noise_gen(path, 15, 400, 0.007, _dp(b))
+    assert a.tolist() == b.tolist() and 0 < a[0] < 400
+
+
+def test_python_run_api(hip, oracle):
+    """ldpc_decode.run(H, LLR, max_iter): the call shape of LDPC_decode.py:348-374."""
+    from ldpc_amd import ldpc_decode
+    from ldpc_amd.alist import alist_to_mat
+    path = code_path("204.33.484.txt")
+    H = alist_to_mat(path)
+    oc = oracle.load(path)
+    rng = np.random.default_rng(8)
+    p = 0.05
+    for trial in range(6):
+        flips = rng.random(oc.n) < (p if trial else 0.0)
+        llr = (1 - 2 * flips.astype(int)) * np.log((1 - p) / p)
+        cw, it, secs = ldpc_decode.run(H, llr, 30)
+        r = oracle.dec_spa(oc, llr.astype(np.float64), np.zeros(oc.m, np.int32), 30)
+        assert cw.shape == (oc.n, 1) and secs >= 0
+        assert (it is False) == (r["rc"] != 0)
+        if it is not False:
+            assert it == r["iters"] and np.array_equal(cw[:, 0], r["bits"])
+    cw, it, _ = ldpc_decode.run(H, np.full(oc.n, 3.0), 30, precheck=True)
+    assert it is True and not cw.any()
+    out = ldpc_decode.run_batch(path, np.full((5, oc.n), 2.5), 10)
+    assert (out["status"] == 0).all() and not out["bits"].any()
