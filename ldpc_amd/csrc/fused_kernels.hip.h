@@ -1,0 +1,429 @@
+// fused_kernels.hip.h -- whole-decode kernel of the Q8.8 min-sum decoder with the
+// frame resident in LDS (gfx950: 160 KiB per CU).
+//
+// dec() of test_code_min_sum_B_fixed.c:192-316 is integer arithmetic once q0 is
+// on the 1/256 grid, and integer sums are associative.  That allows a layout
+// that never materialises the 2E edge messages in memory at all:
+//
+//   LDS     sum[n]  int32   posterior of every variable: q0 + all its c2v
+//   VGPRs   per check (one thread owns a check): the check's c2v messages in
+//           compressed form -- min1, min2, position of min1, one sign bit per
+//           edge -- for the previous and the current iteration
+//
+// One workgroup decodes one frame, start to finish.  Per iteration:
+//   phase A  each check thread walks its edges: reads sum[v], rebuilds its own
+//            previous message c_old (from the compressed state), forms
+//            v2c = sat127(sum[v] - c_old)  (:213-229, float_to_fix :43-53),
+//            accumulates sign parity (with the syndrome bit, :264-267) and
+//            min1/min2 (:269-277) -> the new compressed state.  The same reads
+//            give the syndrome of the current hard decisions (enc() + HamDist,
+//            :308-312) for free.
+//   barrier  (__syncthreads_or of "some check unsatisfied": the exit test)
+//   phase B  each check thread adds (c_new - c_old) into sum[v] of its edges
+//            with LDS integer atomics (ds_add_u32): sum stays q0 + sum of c2v.
+//   barrier
+// All reads of phase A see the sums of the previous iteration, so this is the
+// flooding schedule of the reference, and every value is the reference's value
+// times 256: decoded bits, iteration counts and syndromes are bit-exact.
+// HBM traffic per frame is the LLRs in (2n bytes) and the decisions out.
+//
+// Workgroups are persistent and pull frames from a device counter, so a frame
+// that converges early frees its CU at once (per-frame early exit with no idle
+// lanes).  The edge->variable indices are stored transposed
+// ([round][slot][thread]) so a wavefront reads them as contiguous rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldpc {
+
+struct FusedArgs {
+  const uint16_t *colT;   // [rounds][rmax][block]  variable of (check = round*block + tid, slot)
+  const uint8_t *dcT;     // [rounds][block]        row weight (0: no such check)
+  int n, m, rmax, rounds;
+  int nframes, max_iter;
+  const void *llr;        // [nframes][n], dtype dt (frame-major, as callers hold q0)
+  int dt;                 // ldpc_dtype
+  const uint8_t *synd;    // [nframes][m] or null
+  uint8_t *bits;          // [nframes][n] or null
+  int32_t *iters;         // [nframes] or null
+  uint8_t *sout;          // [nframes][m] or null
+  int32_t *status;        // [nframes] or null
+  float *llr_out;         // [nframes][n] or null
+  int *counter;           // frame queue head (zeroed by the host before the launch)
+};
+
+#define FQ_SAT 32512      /* 127.0 */
+#define FQ_CAP 51200      /* 200.0 */
+
+__device__ __forceinline__ int fq_from_real(double x) {   // float_to_fix(), raw
+  double r = round(x * 256.0);
+  if (r > 127.0 * 256.0) r = 127.0 * 256.0;
+  if (r < -128.0 * 256.0) r = -128.0 * 256.0;
+  return (int)r;
+}
+
+template <typename MaskT> struct CheckState {
+  unsigned mins;   // min1 | min2 << 16  (both <= FQ_CAP < 65536)
+  int arg;         // slot of min1
+  MaskT sg;        // bit k: c2v of slot k is negative
+};
+
+template <typename MaskT>
+__device__ __forceinline__ int cs_msg(const CheckState<MaskT> &s, int k) {
+  const int mag = (k == s.arg) ? (int)(s.mins >> 16) : (int)(s.mins & 0xffffu);
+  return ((s.sg >> k) & 1) ? -mag : mag;
+}
+
+template <int CPT, typename MaskT>
+__global__ __launch_bounds__(1024) void fused_q88_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int sum[];   // [n] (+1 word: frame id)
+  const int tid = threadIdx.x, B = blockDim.x;
+  int *frame_slot = sum + a.n;
+
+  int dc[CPT];
+#pragma unroll
+  for (int r = 0; r < CPT; r++) dc[r] = r < a.rounds ? a.dcT[r * B + tid] : 0;
+
+  for (;;) {
+    __syncthreads();                                   // previous frame fully written out
+    if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+
+    // q0 -> sum  (float_to_fix for real-valued inputs, as the reference's bsc() :117-120)
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 2) {                                 // LDPC_DT_I16 raw Q8.8
+        const short *p = (const short *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) sum[i] = p[i];
+      } else if (a.dt == 3) {                          // LDPC_DT_I32 raw
+        const int *p = (const int *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) {
+          int v = p[i];
+          sum[i] = v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
+        }
+      } else if (a.dt == 1) {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) sum[i] = fq_from_real((double)p[i]);
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) sum[i] = fq_from_real(p[i]);
+      }
+    }
+    CheckState<MaskT> cur[CPT], nxt[CPT];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      cur[r].mins = 0; cur[r].arg = -1; cur[r].sg = 0;
+      nxt[r] = cur[r];
+      const int c = r * B + tid;
+      sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + c] & 1) : 0;
+      par[r] = 0;
+    }
+    __syncthreads();
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      // ---- phase A: check pass on the sums of iteration t-1
+      int bad = 0;
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+        if (r < a.rounds) {
+          const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+          const int d = dc[r];
+          int m1 = FQ_CAP, m2 = FQ_CAP, arg = -1, p = 0;
+          MaskT sg = 0;
+          for (int k = 0; k < d; k++) {
+            const int v = col[(size_t)k * B];
+            const int S = sum[v];
+            p ^= (S < 0);
+            const int q = S - cs_msg(cur[r], k);
+            const int neg = q < 0;
+            int mag = neg ? -q : q;
+            mag = mag > FQ_SAT ? FQ_SAT : mag;
+            sg |= (MaskT)neg << k;
+            if (mag < m1) { m2 = m1; m1 = mag; arg = k; }
+            else if (mag < m2) { m2 = mag; }
+          }
+          par[r] = p;
+          bad |= p ^ sbit[r];
+          // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
+          int tot = sbit[r];
+          if (sizeof(MaskT) == 8) tot ^= __popcll((unsigned long long)sg) & 1;
+          else tot ^= __popc((unsigned)sg) & 1;
+          MaskT all = d >= (int)(8 * sizeof(MaskT)) ? ~(MaskT)0 : (((MaskT)1 << d) - 1);
+          nxt[r].mins = (unsigned)m1 | ((unsigned)m2 << 16);
+          nxt[r].arg = arg;
+          nxt[r].sg = tot ? (sg ^ all) : sg;
+        }
+      }
+      const int any_bad = __syncthreads_or(bad);
+      if (!any_bad) { it_done = t - 1; ok = 1; break; }   // H*bits == s after iteration t-1
+      if (t == a.max_iter + 1) break;
+      // ---- phase B: fold the new messages into the sums
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+        if (r < a.rounds) {
+          const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+          const int d = dc[r];
+          for (int k = 0; k < d; k++) {
+            const int delta = cs_msg(nxt[r], k) - cs_msg(cur[r], k);
+            if (delta) atomicAdd(&sum[col[(size_t)k * B]], delta);
+          }
+          cur[r] = nxt[r];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- outputs of this frame
+    if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = sum[i] < 0;
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) {
+        int s = sum[i];
+        s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);   // sum = float_to_fix(sum), :303
+        o[i] = (float)s * (1.0f / 256.0f);
+      }
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (dc[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+  }
+}
+
+// Same algorithm with the edge->variable indices of a thread's checks held in
+// VGPRs for the life of the (persistent) workgroup: 2 uint16 LDS byte offsets
+// per register, slot loops fully unrolled, so an iteration touches no global
+// memory at all and the LDS reads of a check are issued back to back.
+//   CPT    checks per thread,  R2 = ceil(rmax / 2) registers of indices per check
+//
+// Arithmetic: every Q8.8 value is an integer of magnitude < 2^19, which binary32
+// holds exactly, and so is every sum or difference the decoder forms; the sums
+// stay int32 in LDS (ds_add_u32; LDS float atomics are several times slower)
+// and are converted on the way in and out of a check's arithmetic, which runs
+// on floats holding integers.  That buys the VALU shortcuts the inner loop is
+// built from: |x| and -x are operand modifiers, a sign is moved with one
+// v_bfi, the slot's sign bit is shifted into the mask with one v_alignbit, and
+// min1 / min2 / argmin come from one v_min_u32 + one v_med3_u32 on the key
+// (bits(|q|) | slot): integer-valued floats below 2^19 have at least 5 zero
+// low mantissa bits, so the key orders exactly like (|q|, slot).
+//
+// Slots beyond a check's weight are not predicated (that would cost a wave mask
+// per slot); they point at one of FQ_NDUMMY extra LDS words that hold a huge
+// positive value, which makes them neutral: sign 0, never a minimum.  What phase
+// B adds to the dummies is bounded per iteration; they are re-armed every
+// iteration.
+#define FQ_NDUMMY 256
+#define FQ_BIG (1 << 24)
+#define FQ_PADLIMF 4194304.0f /* 2^22 */
+
+__device__ __forceinline__ unsigned fq_med3u(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fq_finish_minf(float mu) {
+  // min over saturated magnitudes = saturated min; no real edge at all -> 200.0 (:270)
+  return mu >= FQ_PADLIMF ? (float)FQ_CAP : (mu > (float)FQ_SAT ? (float)FQ_SAT : mu);
+}
+// copysign: magnitude bits of mag, sign bit of sw
+__device__ __forceinline__ float fq_withsign(float mag, unsigned sw) {
+  return __uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (sw & 0x80000000u));
+}
+
+// SH: LDS byte offset = index << SH (0 when the offsets themselves fit 16 bits)
+template <int CPT, int R2, int SH, int LB, int MINW>
+__global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int fsum[];   // [n] + dummies + frame id
+  const int tid = threadIdx.x, B = blockDim.x;
+  int *frame_slot = (int *)(fsum + a.n + FQ_NDUMMY);
+  constexpr int RM = 2 * R2;
+  constexpr int CH = RM < 8 ? RM : 8;          // LDS reads in flight per check
+  constexpr int NW = (RM + 31) / 32;           // sign-mask words per check
+  constexpr int WB = RM < 32 ? RM : 32;        // slots per mask word
+  constexpr int KB = RM <= 32 ? 5 : 6;         // key bits that hold the slot
+  constexpr unsigned KM = (1u << KB) - 1;
+  const char *lds = (const char *)fsum;
+
+  int dc[CPT];
+  unsigned idx[CPT][R2];
+  unsigned allm[CPT][NW];                      // mask bits of the real slots
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    dc[r] = r < a.rounds ? a.dcT[r * B + tid] : 0;
+    const unsigned pad = (unsigned)(a.n + (tid & (FQ_NDUMMY - 1)));
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) {
+      unsigned lo = pad, hi = pad;
+      if (r < a.rounds) {
+        const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+        if (2 * k2 < dc[r]) lo = col[(size_t)(2 * k2) * B];
+        if (2 * k2 + 1 < dc[r]) hi = col[(size_t)(2 * k2 + 1) * B];
+      }
+      idx[r][k2] = (lo << (2 - SH)) | ((hi << (2 - SH)) << 16);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      int dw = dc[r] - 32 * w;                 // real slots in this word
+      dw = dw < 0 ? 0 : (dw > WB ? WB : dw);
+      // slot k of the word sits at bit WB-1-k after the alignbit chain
+      allm[r][w] = dw == 0 ? 0u : (dw >= 32 ? ~0u : (((1u << dw) - 1u) << (WB - dw)));
+    }
+  }
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 2) {
+        const short *p = (const short *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) fsum[i] = p[i];
+      } else if (a.dt == 3) {
+        const int *p = (const int *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) {
+          int v = p[i];
+          fsum[i] = v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
+        }
+      } else if (a.dt == 1) {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) fsum[i] = fq_from_real((double)p[i]);
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) fsum[i] = fq_from_real(p[i]);
+      }
+      if (tid < FQ_NDUMMY) fsum[a.n + tid] = FQ_BIG;
+    }
+    // compressed messages of the previous (o*) and the current (n*) iteration
+    float om1[CPT], om2[CPT], nm1[CPT], nm2[CPT];
+    unsigned oarg[CPT], narg[CPT], osg[CPT][NW], nsg[CPT][NW];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      om1[r] = om2[r] = nm1[r] = nm2[r] = 0.0f;
+      oarg[r] = narg[r] = 0xffu;
+#pragma unroll
+      for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w] = 0;
+      sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
+      par[r] = 0;
+    }
+    __syncthreads();
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      int bad = 0;
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+        // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
+        // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) asm volatile("" : "+v"(idx[r][k2]));
+        unsigned k1 = 0xffffffffu, k2m = 0xffffffffu, p = 0, sg[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) sg[w] = 0;
+#pragma unroll
+        for (int kc = 0; kc < RM; kc += CH) {
+          int S[CH];
+#pragma unroll
+          for (int j = 0; j < CH; j++) {
+            const int k = kc + j;
+            const unsigned off = ((k & 1) ? (idx[r][k >> 1] >> 16) : (idx[r][k >> 1] & 0xffffu)) << SH;
+            S[j] = *(const int *)(lds + off);
+          }
+#pragma unroll
+          for (int j = 0; j < CH; j++) {
+            const int k = kc + j;
+            p ^= (unsigned)S[j];
+            const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
+            const float q = (float)S[j] - fq_withsign(mo, osg[r][k / 32] << (32 - WB + (k % 32)));
+            sg[k / 32] = __builtin_amdgcn_alignbit(sg[k / 32], __float_as_uint(q), 31);
+            const unsigned key = (__float_as_uint(q) & 0x7fffffffu) | (unsigned)k;
+            k2m = fq_med3u(k1, key, k2m);
+            k1 = min(k1, key);
+          }
+        }
+        p >>= 31;
+        par[r] = (int)p;
+        bad |= (int)p ^ sbit[r];
+        unsigned tot = (unsigned)sbit[r];
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[w]);
+        nm1[r] = fq_finish_minf(__uint_as_float(k1 & ~KM));
+        nm2[r] = fq_finish_minf(__uint_as_float(k2m & ~KM));
+        narg[r] = k1 & KM;
+        // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
+#pragma unroll
+        for (int w = 0; w < NW; w++) nsg[r][w] = (tot & 1) ? (sg[w] ^ allm[r][w]) : sg[w];
+        // materialise the compressed state now: left alone the compiler carries the 2*R2
+        // per-slot values of this check across the barrier instead (register spills)
+        asm volatile("" : "+v"(nm1[r]), "+v"(nm2[r]), "+v"(narg[r]));
+#pragma unroll
+        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nsg[r][w]));
+      }
+      const int any_bad = __syncthreads_or(bad);
+      if (!any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      if (tid < FQ_NDUMMY) fsum[a.n + tid] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) asm volatile("" : "+v"(idx[r][k2]));
+        asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]));   // rebuild c_old from the state
+#pragma unroll
+        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]));
+#pragma unroll
+        for (int k = 0; k < RM; k++) {
+          const unsigned off = ((k & 1) ? (idx[r][k >> 1] >> 16) : (idx[r][k >> 1] & 0xffffu)) << SH;
+          const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
+          const float mn = ((unsigned)k == narg[r]) ? nm2[r] : nm1[r];
+          const int sh = 32 - WB + (k % 32);
+          const float delta = fq_withsign(mn, nsg[r][k / 32] << sh) - fq_withsign(mo, osg[r][k / 32] << sh);
+          atomicAdd((int *)(lds + off), (int)delta);
+        }
+        om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r];
+#pragma unroll
+        for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w];
+      }
+      __syncthreads();
+    }
+
+    if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = fsum[i] < 0;
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) {
+        int s = fsum[i];
+        s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);   // float_to_fix(sum), :303
+        o[i] = (float)s * (1.0f / 256.0f);
+      }
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (dc[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+  }
+}
+
+}  // namespace ldpc

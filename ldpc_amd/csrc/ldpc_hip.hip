@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "binary_kernels.hip.h"
+#include "fused_kernels.hip.h"
 #include "engine.h"
 #include "graph.h"
 
@@ -572,6 +573,160 @@ struct BinaryEngine : Engine {
   }
 };
 
+
+// Q8.8 min-sum with the frame resident in LDS (fused_kernels.hip.h): one launch
+// per decode call, no workspace in HBM besides the frame queue head.
+struct FusedQ88Engine : Engine {
+  ldpc_opts opts{};
+  int n = 0, m = 0, rmax = 0;
+  int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
+  size_t lds = 0;
+  DevBuf d_colT, d_dcT, d_counter;
+  void (*kern)(FusedArgs) = nullptr;
+
+  static bool fits(const ldpc_code &c) {
+    return c.q == 2 && c.n <= 65535 && c.rmax <= 64 && (size_t)(c.n + FQ_NDUMMY + 4) * 4 <= 160 * 1024 &&
+           (c.m + 63) / 64 <= 8 * 16;
+  }
+  size_t llr_elems_per_frame() const override { return (size_t)n; }
+
+  template <typename MaskT>
+  static void (*pick(int cpt))(FusedArgs) {
+    switch (cpt) {
+      case 1: return fused_q88_kernel<1, MaskT>;
+      case 2: return fused_q88_kernel<2, MaskT>;
+      case 3: return fused_q88_kernel<3, MaskT>;
+      case 4: return fused_q88_kernel<4, MaskT>;
+      case 5: return fused_q88_kernel<5, MaskT>;
+      case 6: return fused_q88_kernel<6, MaskT>;
+      default: return fused_q88_kernel<8, MaskT>;
+    }
+  }
+
+  template <int R2, int SH, int LB, int MINW>
+  static void (*pick_reg(int cpt))(FusedArgs) {
+    switch (cpt) {
+      case 1: return fused_q88_reg_kernel<1, R2, SH, LB, MINW>;
+      case 2: return fused_q88_reg_kernel<2, R2, SH, LB, MINW>;
+      case 3: return fused_q88_reg_kernel<3, R2, SH, LB, MINW>;
+      default: return nullptr;
+    }
+  }
+  template <int SH, int LB, int MINW>
+  static void (*pick_reg_r(int cpt, int rmax))(FusedArgs) {
+    if (rmax <= 8) return pick_reg<4, SH, LB, MINW>(cpt);
+    if (rmax <= 16) return pick_reg<8, SH, LB, MINW>(cpt);
+    if (rmax <= 32) return pick_reg<16, SH, LB, MINW>(cpt);
+    if (rmax <= 64) return pick_reg<32, SH, LB, MINW>(cpt);
+    return nullptr;
+  }
+
+  int init(const ldpc_code &c, const ldpc_opts &o) override {
+    opts = o;
+    n = c.n; m = c.m; rmax = c.rmax;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, o.device));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    lds = (size_t)(n + FQ_NDUMMY + 4) * 4;
+    wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu > 4) wg_per_cu = 4;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    // Workgroup shape.  First choice: the register-cached kernel (<= 3 checks per thread,
+    // <= 16 waves per CU so that every wave gets 128 VGPRs); waves should own equal
+    // numbers of checks.  Otherwise the generic kernel (indices re-read every iteration).
+    const int need = (m + 63) / 64;
+    const int r2 = (rmax + 1) / 2;
+    int env_w = 0, env_g = 0, env_reg = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_WAVES")) env_w = atoi(e);
+    if (const char *e = getenv("LDPC_HIP_FUSED_WG_PER_CU")) env_g = atoi(e);
+    if (const char *e = getenv("LDPC_HIP_FUSED_REG")) env_reg = atoi(e);
+    int bestW = 0, bestG = 0;
+    double best = -1;
+    bool use_reg = false;
+    if (env_reg && rmax <= 64) {
+      for (int G = 1; G <= wg_per_cu; G++)
+        for (int W = 1; W * G <= 16; W++) {
+          if (env_w && W != env_w) continue;
+          if (env_g && G != env_g) continue;
+          const int r = (need + W - 1) / W;
+          if (r > 3 || r * r2 > 64) continue;
+          const double score = (double)need / ((double)r * W) + 0.01 * W * G + 0.005 * G;
+          if (score > best) { best = score; bestW = W; bestG = G; }
+        }
+      use_reg = bestW > 0;
+    }
+    if (!use_reg) {
+      bestG = env_g >= 1 && env_g <= wg_per_cu ? env_g : wg_per_cu;
+      const int maxW = bestG >= 2 ? 8 : 16;
+      for (int W = maxW; W >= 1; W--) {
+        if (env_w && W != env_w) continue;
+        const int r = (need + W - 1) / W;
+        if (r > 8) break;
+        const double score = (double)need / ((double)r * W) + 1e-3 * W;
+        if (score > best) { best = score; bestW = W; }
+      }
+      if (!bestW) bestW = 16;
+    }
+    wg_per_cu = bestG;
+    block = bestW * 64;
+    rounds = (m + block - 1) / block;
+    if (use_reg) {
+      const bool small = (size_t)(n + FQ_NDUMMY) * 4 <= 65536;   // byte offsets fit 16 bits
+      kern = small ? pick_reg_r<0, 1024, 4>(rounds, rmax) : pick_reg_r<2, 1024, 4>(rounds, rmax);
+    } else {
+      int cpt = rounds;
+      if (cpt == 7) cpt = 8;
+      kern = rmax <= 32 ? pick<uint32_t>(cpt) : pick<unsigned long long>(cpt);
+    }
+    if (!kern) { ldpc_set_error("no fused kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<uint16_t> colT((size_t)rounds * rmax * block, 0);
+    std::vector<uint8_t> dcT((size_t)rounds * block, 0);
+    for (int j = 0; j < m; j++) {
+      const int r = j / block, t = j % block;
+      const int d = c.row_ptr[j + 1] - c.row_ptr[j];
+      dcT[(size_t)r * block + t] = (uint8_t)d;
+      for (int k = 0; k < d; k++)
+        colT[((size_t)r * rmax + k) * block + t] = (uint16_t)c.col_idx[c.row_ptr[j] + k];
+    }
+    int rc;
+    if ((rc = d_colT.ensure(colT.size() * 2))) return rc;
+    if ((rc = d_dcT.ensure(dcT.size()))) return rc;
+    if ((rc = d_counter.ensure(256))) return rc;
+    HIPCHK(hipMemcpy(d_colT.p, colT.data(), colT.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_dcT.p, dcT.data(), dcT.size(), hipMemcpyHostToDevice));
+    return LDPC_OK;
+  }
+
+  int decode(int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter, uint8_t *bits,
+             int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out, hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
+    if (!llr || max_iter < 0 || max_iter > 65000 || dt < 0 || dt > 3) {
+      ldpc_set_error("bad arguments to the fused Q8.8 decoder");
+      return LDPC_ERR_ARG;
+    }
+    HIPCHK(hipMemsetAsync(d_counter.p, 0, 4, st));
+    if (sout) HIPCHK(hipMemsetAsync(sout, 0, (size_t)nframes * m, st));
+    FusedArgs a;
+    a.colT = d_colT.as<uint16_t>();
+    a.dcT = d_dcT.as<uint8_t>();
+    a.n = n; a.m = m; a.rmax = rmax; a.rounds = rounds;
+    a.nframes = nframes; a.max_iter = max_iter;
+    a.llr = llr; a.dt = dt; a.synd = sy;
+    a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
+    a.counter = d_counter.as<int>();
+    long grid = (long)num_cu * wg_per_cu;
+    if (grid > nframes) grid = nframes;
+    prof_begin(K_FUSED, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
+    LAUNCHCHK("fused_q88_kernel");
+    prof_end(st);
+    last_iterations = max_iter;
+    return LDPC_OK;
+  }
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------- decoder
@@ -580,6 +735,7 @@ struct ldpc_decoder {
   ldpc_code code;
   ldpc_opts opts{};
   std::unique_ptr<Engine> eng;
+  std::unique_ptr<Engine> trace_eng;   // two-pass Q8.8 engine, made on the first trace call
   // staging for the host-pointer entry point
   DevBuf s_llr, s_synd, s_bits, s_sout, s_iters, s_status, s_post;
   int max_frames = 0;
@@ -609,9 +765,14 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
     case LDPC_ALG_MINSUM_F64: if (binary) d->eng.reset(new BinaryEngine<double, ALG_MS>); break;
     case LDPC_ALG_MINSUM_Q88:
       if (binary) {
+        // cn_variant 0: frame-resident fused kernel when the code fits in LDS;
+        // any other value (or LDPC_HIP_FUSED=0) selects the two-pass HBM engine
+        bool fused = opts->cn_variant == 0 && FusedQ88Engine::fits(*c);
+        if (const char *e = getenv("LDPC_HIP_FUSED")) fused = fused && atoi(e) != 0;
+        if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which
         // does not fit an int16 Q8.8 message: such codes use int32 messages
-        if (c->min_row_weight >= 2) d->eng.reset(new BinaryEngine<short, ALG_MSQ>);
+        else if (c->min_row_weight >= 2) d->eng.reset(new BinaryEngine<short, ALG_MSQ>);
         else d->eng.reset(new BinaryEngine<int, ALG_MSQ>);
       }
       break;
@@ -744,7 +905,21 @@ extern "C" int ldpc_decode_trace_q88(ldpc_decoder *d, const void *llr, int llr_d
     ldpc_set_error(std::string("cannot open trace file ") + trace_path);
     return LDPC_ERR_IO;
   }
-  rc = d->eng->decode_traced(d->s_llr.p, llr_dtype, syndrome ? d->s_synd.as<uint8_t>() : nullptr, max_iter,
+  Engine *te = d->eng.get();
+  if (d->opts.alg == LDPC_ALG_MINSUM_Q88 && dynamic_cast<FusedQ88Engine *>(te)) {
+    if (!d->trace_eng) {
+      std::unique_ptr<Engine> e;
+      if (d->code.min_row_weight >= 2) e.reset(new BinaryEngine<short, ALG_MSQ>);
+      else e.reset(new BinaryEngine<int, ALG_MSQ>);
+      ldpc_opts o = d->opts;
+      o.max_frames = 64;
+      o.want_llr = 0;
+      if ((rc = e->init(d->code, o))) { fclose(fp); return rc; }
+      d->trace_eng = std::move(e);
+    }
+    te = d->trace_eng.get();
+  }
+  rc = te->decode_traced(d->s_llr.p, llr_dtype, syndrome ? d->s_synd.as<uint8_t>() : nullptr, max_iter,
                              d->s_bits.as<uint8_t>(), d->s_iters.as<int32_t>(), d->s_sout.as<uint8_t>(),
                              d->s_status.as<int32_t>(), fp, circ_size);
   fclose(fp);
