@@ -172,6 +172,14 @@ int ldpc_decode_trace_q88(ldpc_decoder *d, const void *llr, int llr_dtype, const
  * iterations actually executed per pass, kernel launches. */
 int ldpc_decoder_last_iterations(const ldpc_decoder *d);
 
+/* Diagnostics of the fused Q8.8 decoder's LDS placement (no counterpart in the
+ * reference): builds the schedule for workgroups of `block` threads and returns
+ * stats[5] = {extra LDS cycles from bank conflicts per pass over the graph,
+ * half-wave accesses per pass, LDS words used, slots per check, self-check
+ * errors (must be 0)}.  optimise = 0 gives the natural layout for comparison.
+ * Host only; needs no GPU. */
+int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, int64_t *stats);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only
  * instrumentation is clock() around the trial loop, test_code_B.c:334,354-356).
  * With profiling enabled every launch of the decoding kernels is bracketed by a

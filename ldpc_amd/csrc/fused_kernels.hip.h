@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ldpc {
 
 struct FusedArgs {
@@ -51,7 +53,18 @@ struct FusedArgs {
   int32_t *status;        // [nframes] or null
   float *llr_out;         // [nframes][n] or null
   int *counter;           // frame queue head (zeroed by the host before the launch)
+  // register-cached kernel only (lds_schedule.cpp): colT/dcT are then [rounds][RM][block]
+  // LDS words (pads already point at dummy words)
+  const uint16_t *pos;    // [n] variable -> LDS word
+  const uint32_t *maskT;  // [rounds][block][nw] sign-mask bits of the real slots
+  int words, dummy_base, ndummy;
 };
+
+// timing experiments only (results wrong when non-zero): 1 no adds, 2 no reads, 4 no barriers
+// inside the iteration loop, 8 conflict-free read addresses, 16 conflict-free add addresses
+#ifndef LDPC_FUSED_ABLATE
+#define LDPC_FUSED_ABLATE 0
+#endif
 
 #define FQ_SAT 32512      /* 127.0 */
 #define FQ_CAP 51200      /* 200.0 */
@@ -243,12 +256,36 @@ __device__ __forceinline__ float fq_withsign(float mag, unsigned sw) {
   return __uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (sw & 0x80000000u));
 }
 
+// magnitude (>= 0, so no sign to clear) with the sign bit of sw
+__device__ __forceinline__ float fq_signed(float mag, unsigned sw) {
+  return __uint_as_float(__float_as_uint(mag) | (sw & 0x80000000u));
+}
+
+// LDS byte address of one of the two 16-bit entries packed in `packed`, by a volatile asm:
+// the unpacking cannot be hoisted out of the iteration loop (which would cost a register
+// per slot) and, unlike an empty asm that "modifies" the packed word, leaves the index
+// registers untouched (no copies).  SH = 0: entries are byte offsets; SH = 2: word indices.
+typedef __attribute__((address_space(3))) int lds_int;
+template <int HI, int SH>
+__device__ __forceinline__ lds_int *fq_slot_ptr(unsigned base, unsigned packed) {
+  unsigned r;
+  if (SH == 0) {
+    if (HI) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(base), "v"(packed));
+    else asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(base), "v"(packed));
+  } else {
+    if (HI) asm volatile("v_lshrrev_b32 %0, 14, %1\n\tv_and_b32 %0, 0x3fffc, %0" : "=&v"(r) : "v"(packed));
+    else asm volatile("v_lshlrev_b32 %0, 2, %1\n\tv_and_b32 %0, 0x3fffc, %0" : "=&v"(r) : "v"(packed));
+    r += base;
+  }
+  return (lds_int *)(unsigned long)r;
+}
+
 // SH: LDS byte offset = index << SH (0 when the offsets themselves fit 16 bits)
 template <int CPT, int R2, int SH, int LB, int MINW>
 __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) int fsum[];   // [n] + dummies + frame id
   const int tid = threadIdx.x, B = blockDim.x;
-  int *frame_slot = (int *)(fsum + a.n + FQ_NDUMMY);
+  int *frame_slot = (int *)(fsum + a.words);
   constexpr int RM = 2 * R2;
   constexpr int CH = RM < 8 ? RM : 8;          // LDS reads in flight per check
   constexpr int NW = (RM + 31) / 32;           // sign-mask words per check
@@ -256,6 +293,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
   constexpr int KB = RM <= 32 ? 5 : 6;         // key bits that hold the slot
   constexpr unsigned KM = (1u << KB) - 1;
   const char *lds = (const char *)fsum;
+  const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)fsum;
 
   int dc[CPT];
   unsigned idx[CPT][R2];
@@ -263,24 +301,18 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #pragma unroll
   for (int r = 0; r < CPT; r++) {
     dc[r] = r < a.rounds ? a.dcT[r * B + tid] : 0;
-    const unsigned pad = (unsigned)(a.n + (tid & (FQ_NDUMMY - 1)));
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) {
-      unsigned lo = pad, hi = pad;
+      unsigned lo = (unsigned)a.dummy_base, hi = (unsigned)a.dummy_base;
       if (r < a.rounds) {
-        const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
-        if (2 * k2 < dc[r]) lo = col[(size_t)(2 * k2) * B];
-        if (2 * k2 + 1 < dc[r]) hi = col[(size_t)(2 * k2 + 1) * B];
+        const uint16_t *col = a.colT + (size_t)r * RM * B + tid;
+        lo = col[(size_t)(2 * k2) * B];
+        hi = col[(size_t)(2 * k2 + 1) * B];
       }
       idx[r][k2] = (lo << (2 - SH)) | ((hi << (2 - SH)) << 16);
     }
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-      int dw = dc[r] - 32 * w;                 // real slots in this word
-      dw = dw < 0 ? 0 : (dw > WB ? WB : dw);
-      // slot k of the word sits at bit WB-1-k after the alignbit chain
-      allm[r][w] = dw == 0 ? 0u : (dw >= 32 ? ~0u : (((1u << dw) - 1u) << (WB - dw)));
-    }
+    for (int w = 0; w < NW; w++) allm[r][w] = r < a.rounds ? a.maskT[((size_t)r * B + tid) * NW + w] : 0u;
   }
 
   for (;;) {
@@ -293,30 +325,32 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       const size_t base = (size_t)frame * a.n;
       if (a.dt == 2) {
         const short *p = (const short *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[i] = p[i];
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = p[i];
       } else if (a.dt == 3) {
         const int *p = (const int *)a.llr + base;
         for (int i = tid; i < a.n; i += B) {
           int v = p[i];
-          fsum[i] = v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
+          fsum[a.pos[i]] = v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
         }
       } else if (a.dt == 1) {
         const float *p = (const float *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[i] = fq_from_real((double)p[i]);
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = fq_from_real((double)p[i]);
       } else {
         const double *p = (const double *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[i] = fq_from_real(p[i]);
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = fq_from_real(p[i]);
       }
-      if (tid < FQ_NDUMMY) fsum[a.n + tid] = FQ_BIG;
+      for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // dummies
     }
     // compressed messages of the previous (o*) and the current (n*) iteration
     float om1[CPT], om2[CPT], nm1[CPT], nm2[CPT];
     unsigned oarg[CPT], narg[CPT], osg[CPT][NW], nsg[CPT][NW];
+    unsigned ooff[CPT], noff[CPT];             // LDS byte offsets of the variables in slots oarg / narg
     int sbit[CPT], par[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; r++) {
       om1[r] = om2[r] = nm1[r] = nm2[r] = 0.0f;
       oarg[r] = narg[r] = 0xffu;
+      ooff[r] = noff[r] = (unsigned)a.dummy_base * 4u;
 #pragma unroll
       for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w] = 0;
       sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
@@ -327,89 +361,119 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     int it_done = a.max_iter, ok = 0;
     for (int t = 1; t <= a.max_iter + 1; t++) {
       int bad = 0;
+      // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
+      // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
+      unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW];
 #pragma unroll
       for (int r = 0; r < CPT; r++) {
-        // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
-        // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
+        k1[r] = k2m[r] = 0xffffffffu;
+        pp[r] = 0;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) asm volatile("" : "+v"(idx[r][k2]));
-        unsigned k1 = 0xffffffffu, k2m = 0xffffffffu, p = 0, sg[NW];
+        for (int w = 0; w < NW; w++) sg[r][w] = 0;
+      }
+      // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
+      // reads in flight and CPT independent min chains
 #pragma unroll
-        for (int w = 0; w < NW; w++) sg[w] = 0;
+      for (int kc = 0; kc < RM; kc += CH) {
+        int S[CPT][CH];
 #pragma unroll
-        for (int kc = 0; kc < RM; kc += CH) {
-          int S[CH];
+        for (int r = 0; r < CPT; r++)
 #pragma unroll
           for (int j = 0; j < CH; j++) {
             const int k = kc + j;
-            const unsigned off = ((k & 1) ? (idx[r][k >> 1] >> 16) : (idx[r][k >> 1] & 0xffffu)) << SH;
-            S[j] = *(const int *)(lds + off);
+            S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
           }
 #pragma unroll
-          for (int j = 0; j < CH; j++) {
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+          for (int r = 0; r < CPT; r++) {
             const int k = kc + j;
-            p ^= (unsigned)S[j];
+            pp[r] ^= (unsigned)S[r][j];
             const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-            const float q = (float)S[j] - fq_withsign(mo, osg[r][k / 32] << (32 - WB + (k % 32)));
-            sg[k / 32] = __builtin_amdgcn_alignbit(sg[k / 32], __float_as_uint(q), 31);
+            const float q = (float)S[r][j] - fq_signed(mo, osg[r][k / 32] << (32 - WB + (k % 32)));
+            sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
             const unsigned key = (__float_as_uint(q) & 0x7fffffffu) | (unsigned)k;
-            k2m = fq_med3u(k1, key, k2m);
-            k1 = min(k1, key);
+            k2m[r] = fq_med3u(k1[r], key, k2m[r]);
+            k1[r] = min(k1[r], key);
           }
-        }
-        p >>= 31;
+      }
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+        const unsigned p = pp[r] >> 31;
         par[r] = (int)p;
         bad |= (int)p ^ sbit[r];
         unsigned tot = (unsigned)sbit[r];
 #pragma unroll
-        for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[w]);
-        nm1[r] = fq_finish_minf(__uint_as_float(k1 & ~KM));
-        nm2[r] = fq_finish_minf(__uint_as_float(k2m & ~KM));
-        narg[r] = k1 & KM;
+        for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[r][w]);
+        nm1[r] = fq_finish_minf(__uint_as_float(k1[r] & ~KM));
+        nm2[r] = fq_finish_minf(__uint_as_float(k2m[r] & ~KM));
+        narg[r] = k1[r] & KM;
+        // where slot narg's variable lives (needed by phase B's fix-up; the load hides under the barrier)
+        {
+          // opaque pointer: keeps the compiler from relating this load to the index registers
+          const uint16_t *ct = a.colT;
+          asm volatile("" : "+s"(ct));
+          const int rr = r < a.rounds ? r : a.rounds - 1;
+          noff[r] = (unsigned)ct[((size_t)rr * RM + narg[r]) * B + tid] * 4u;
+        }
         // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
 #pragma unroll
-        for (int w = 0; w < NW; w++) nsg[r][w] = (tot & 1) ? (sg[w] ^ allm[r][w]) : sg[w];
+        for (int w = 0; w < NW; w++) nsg[r][w] = (tot & 1) ? (sg[r][w] ^ allm[r][w]) : sg[r][w];
         // materialise the compressed state now: left alone the compiler carries the 2*R2
         // per-slot values of this check across the barrier instead (register spills)
         asm volatile("" : "+v"(nm1[r]), "+v"(nm2[r]), "+v"(narg[r]));
 #pragma unroll
         for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nsg[r][w]));
       }
-      const int any_bad = __syncthreads_or(bad);
+      const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : __syncthreads_or(bad);
       if (!any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
-      if (tid < FQ_NDUMMY) fsum[a.n + tid] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
+      for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
+      // ---- phase B.  delta_k = c_new_k - c_old_k with c = +-min1 everywhere except in the
+      // slot of min1 itself, where it is +-min2.  The slot loop treats every slot as
+      // "+-min1" (integer arithmetic on sign masks, no per-slot selects) and the two
+      // exceptional slots are put right afterwards by one extra add each.
 #pragma unroll
       for (int r = 0; r < CPT; r++) {
+        // (re)derive everything from the compressed state here, not before the barrier
+        asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]));
 #pragma unroll
-        for (int k2 = 0; k2 < R2; k2++) asm volatile("" : "+v"(idx[r][k2]));
-        asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]));   // rebuild c_old from the state
-#pragma unroll
-        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]));
+        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]), "+v"(nsg[r][w]));
+        const int m1o = (int)om1[r], m1n = (int)nm1[r];
 #pragma unroll
         for (int k = 0; k < RM; k++) {
-          const unsigned off = ((k & 1) ? (idx[r][k >> 1] >> 16) : (idx[r][k >> 1] & 0xffffu)) << SH;
-          const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-          const float mn = ((unsigned)k == narg[r]) ? nm2[r] : nm1[r];
-          const int sh = 32 - WB + (k % 32);
-          const float delta = fq_withsign(mn, nsg[r][k / 32] << sh) - fq_withsign(mo, osg[r][k / 32] << sh);
-          atomicAdd((int *)(lds + off), (int)delta);
+          lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
+          const int pos = WB - 1 - (k % 32);
+          const int sn = __builtin_amdgcn_sbfe((int)nsg[r][k / 32], pos, 1);   // 0 or -1
+          const int so = __builtin_amdgcn_sbfe((int)osg[r][k / 32], pos, 1);
+          const int delta = ((m1n ^ sn) - sn) - ((m1o ^ so) - so);
+          __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
         }
-        om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r];
+        {
+          // slot oarg really carried +-min2 before; slot narg carries +-min2 now
+          const int dmo = (int)om2[r] - m1o, dmn = (int)nm2[r] - m1n;
+          const unsigned ao = oarg[r] & (RM - 1), an = narg[r] & (RM - 1);
+          const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
+          const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
+          atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
+          atomicAdd((int *)(lds + noff[r]), (dmn ^ sn) - sn);
+        }
+        om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
 #pragma unroll
         for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w];
       }
-      __syncthreads();
+      if (!(LDPC_FUSED_ABLATE & 4)) __syncthreads();
     }
 
     if (a.bits) {
       uint8_t *o = a.bits + (size_t)frame * a.n;
-      for (int i = tid; i < a.n; i += B) o[i] = fsum[i] < 0;
+      for (int i = tid; i < a.n; i += B) o[i] = fsum[a.pos[i]] < 0;
     }
     if (a.llr_out) {
       float *o = a.llr_out + (size_t)frame * a.n;
       for (int i = tid; i < a.n; i += B) {
-        int s = fsum[i];
+        int s = fsum[a.pos[i]];
         s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);   // float_to_fix(sum), :303
         o[i] = (float)s * (1.0f / 256.0f);
       }

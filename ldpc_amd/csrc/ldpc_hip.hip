@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include "fused_kernels.hip.h"
 #include "engine.h"
 #include "graph.h"
+#include "lds_schedule.h"
 
 // ------------------------------------------------------------------ errors
 
@@ -581,7 +583,9 @@ struct FusedQ88Engine : Engine {
   int n = 0, m = 0, rmax = 0;
   int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
   size_t lds = 0;
-  DevBuf d_colT, d_dcT, d_counter;
+  DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT;
+  LdsSchedule sched;
+  bool use_reg = false;
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
@@ -642,7 +646,7 @@ struct FusedQ88Engine : Engine {
     if (const char *e = getenv("LDPC_HIP_FUSED_REG")) env_reg = atoi(e);
     int bestW = 0, bestG = 0;
     double best = -1;
-    bool use_reg = false;
+    use_reg = false;
     if (env_reg && rmax <= 64) {
       for (int G = 1; G <= wg_per_cu; G++)
         for (int W = 1; W * G <= 16; W++) {
@@ -670,32 +674,49 @@ struct FusedQ88Engine : Engine {
     wg_per_cu = bestG;
     block = bestW * 64;
     rounds = (m + block - 1) / block;
+    int rc;
     if (use_reg) {
-      const bool small = (size_t)(n + FQ_NDUMMY) * 4 <= 65536;   // byte offsets fit 16 bits
+      const int RM = rmax <= 8 ? 8 : rmax <= 16 ? 16 : rmax <= 32 ? 32 : 64;
+      int optimise = 1;
+      if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
+      if (ldpc_build_lds_schedule(c, block, RM, FQ_NDUMMY, optimise != 0, sched)) {
+        ldpc_set_error("LDS schedule: code too large");
+        return LDPC_ERR_UNSUPPORTED;
+      }
+      lds = (size_t)(sched.words + 4) * 4;
+      const bool small = (size_t)sched.words * 4 <= 65536;   // byte offsets fit 16 bits
       kern = small ? pick_reg_r<0, 1024, 4>(rounds, rmax) : pick_reg_r<2, 1024, 4>(rounds, rmax);
+      if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
+      if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
+      if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
+      if ((rc = d_maskT.ensure(sched.maskT.size() * 4))) return rc;
+      HIPCHK(hipMemcpy(d_colT.p, sched.colT.data(), sched.colT.size() * 2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_dcT.p, sched.dcT.data(), sched.dcT.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_pos.p, sched.pos.data(), sched.pos.size() * 2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_maskT.p, sched.maskT.data(), sched.maskT.size() * 4, hipMemcpyHostToDevice));
     } else {
       int cpt = rounds;
       if (cpt == 7) cpt = 8;
       kern = rmax <= 32 ? pick<uint32_t>(cpt) : pick<unsigned long long>(cpt);
+      std::vector<uint16_t> colT((size_t)rounds * rmax * block, 0);
+      std::vector<uint8_t> dcT((size_t)rounds * block, 0);
+      for (int j = 0; j < m; j++) {
+        const int r = j / block, t = j % block;
+        const int d = c.row_ptr[j + 1] - c.row_ptr[j];
+        dcT[(size_t)r * block + t] = (uint8_t)d;
+        for (int k = 0; k < d; k++)
+          colT[((size_t)r * rmax + k) * block + t] = (uint16_t)c.col_idx[c.row_ptr[j] + k];
+      }
+      if ((rc = d_colT.ensure(colT.size() * 2))) return rc;
+      if ((rc = d_dcT.ensure(dcT.size()))) return rc;
+      HIPCHK(hipMemcpy(d_colT.p, colT.data(), colT.size() * 2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_dcT.p, dcT.data(), dcT.size(), hipMemcpyHostToDevice));
     }
     if (!kern) { ldpc_set_error("no fused kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
+    if (lds > 160 * 1024) { ldpc_set_error("fused decoder: frame does not fit in LDS"); return LDPC_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    std::vector<uint16_t> colT((size_t)rounds * rmax * block, 0);
-    std::vector<uint8_t> dcT((size_t)rounds * block, 0);
-    for (int j = 0; j < m; j++) {
-      const int r = j / block, t = j % block;
-      const int d = c.row_ptr[j + 1] - c.row_ptr[j];
-      dcT[(size_t)r * block + t] = (uint8_t)d;
-      for (int k = 0; k < d; k++)
-        colT[((size_t)r * rmax + k) * block + t] = (uint16_t)c.col_idx[c.row_ptr[j] + k];
-    }
-    int rc;
-    if ((rc = d_colT.ensure(colT.size() * 2))) return rc;
-    if ((rc = d_dcT.ensure(dcT.size()))) return rc;
     if ((rc = d_counter.ensure(256))) return rc;
-    HIPCHK(hipMemcpy(d_colT.p, colT.data(), colT.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_dcT.p, dcT.data(), dcT.size(), hipMemcpyHostToDevice));
     return LDPC_OK;
   }
 
@@ -716,6 +737,9 @@ struct FusedQ88Engine : Engine {
     a.llr = llr; a.dt = dt; a.synd = sy;
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
     a.counter = d_counter.as<int>();
+    a.pos = d_pos.as<uint16_t>();
+    a.maskT = d_maskT.as<uint32_t>();
+    a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
     prof_begin(K_FUSED, st);
@@ -801,6 +825,36 @@ extern "C" void ldpc_decoder_free(ldpc_decoder *d) {
   (void)hipSetDevice(d->opts.device);
   (void)hipDeviceSynchronize();
   delete d;
+}
+
+extern "C" int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, int64_t *stats) {
+  if (!c || !stats || block <= 0 || block % 64 || c->rmax > 64) return LDPC_ERR_ARG;
+  const int RM = c->rmax <= 8 ? 8 : c->rmax <= 16 ? 16 : c->rmax <= 32 ? 32 : 64;
+  LdsSchedule s;
+  if (ldpc_build_lds_schedule(*c, block, RM, FQ_NDUMMY, optimise != 0, s)) return LDPC_ERR_UNSUPPORTED;
+  stats[0] = s.conflicts; stats[1] = s.accesses; stats[2] = s.words; stats[3] = s.RM;
+  // self-check: every edge appears exactly once in its check's slots
+  std::vector<int> inv(s.words, -1);
+  for (int v = 0; v < c->n; v++) {
+    if (inv[s.pos[v]] >= 0) return LDPC_ERR_FORMAT;
+    inv[s.pos[v]] = v;
+  }
+  int64_t bad = 0;
+  for (int j = 0; j < c->m; j++) {
+    std::vector<int> want(c->col_idx.begin() + c->row_ptr[j], c->col_idx.begin() + c->row_ptr[j + 1]), got;
+    const int r = j / block, t = j % block;
+    for (int k = 0; k < RM; k++) {
+      const int w = s.colT[((size_t)r * RM + k) * block + t];
+      const bool real = (s.maskT[((size_t)r * block + t) * s.nw + k / 32] >> ((RM < 32 ? RM : 32) - 1 - (k % 32))) & 1u;
+      if (real != (w < s.dummy_base)) bad++;
+      if (w < s.dummy_base) got.push_back(inv[w]);
+    }
+    std::sort(want.begin(), want.end());
+    std::sort(got.begin(), got.end());
+    if (want != got) bad++;
+  }
+  stats[4] = bad;
+  return LDPC_OK;
 }
 
 extern "C" int ldpc_decoder_profile(ldpc_decoder *d, int enable) {

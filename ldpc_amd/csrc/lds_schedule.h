@@ -1,0 +1,21 @@
+// lds_schedule.h -- LDS placement / slot schedule of the fused decoder (lds_schedule.cpp)
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "graph.h"
+
+struct LdsSchedule {
+  int block = 0, rounds = 0, RM = 0, nw = 1;
+  int var_words = 0, dummy_base = 0, ndummy = 0, words = 0;
+  std::vector<uint16_t> pos;     // [n]  variable -> LDS word
+  std::vector<uint16_t> colT;    // [rounds][RM][block]  LDS word visited by (check, slot)
+  std::vector<uint32_t> maskT;   // [rounds][block][nw]  sign-mask bits of the real slots
+  std::vector<uint8_t> dcT;      // [rounds][block]      row weight (0: no such check)
+  long conflicts = 0, accesses = 0;   // extra LDS cycles / half-wave accesses per iteration pass
+};
+
+// block: threads per workgroup (multiple of 64); RM: slots per check (even, >= rmax);
+// ndummy: dummy words (multiple of 32).  optimise = false keeps the natural layout.
+int ldpc_build_lds_schedule(const ldpc_code &c, int block, int RM, int ndummy, bool optimise,
+                            LdsSchedule &out);

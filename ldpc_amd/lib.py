@@ -74,6 +74,7 @@ def load_library():
     L.ldpc_decode_batch.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp]
     L.ldpc_decode_batch_device.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ldpc_decode_trace_q88.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, vp, cp, ip]
+    L.ldpc_code_lds_schedule_stats.argtypes = [vp, ip, ip, vp]
     L.ldpc_decoder_profile.argtypes = [vp, ip]
     L.ldpc_decoder_profile_read.argtypes = [vp, vp, vp]
     L.ldpc_set_seed.argtypes = [C.c_uint64]
@@ -160,6 +161,11 @@ class Code:
         s = np.zeros(self.m, np.int32)
         check(load_library().ldpc_code_syndrome(self._h, _ptr(x), _ptr(s)))
         return s
+
+    def lds_schedule_stats(self, block, optimise=True):
+        st = np.zeros(5, np.int64)
+        check(load_library().ldpc_code_lds_schedule_stats(self._h, int(block), int(optimise), _ptr(st)))
+        return dict(conflicts=int(st[0]), accesses=int(st[1]), words=int(st[2]), slots=int(st[3]), errors=int(st[4]))
 
     def close(self):
         if self._h:
