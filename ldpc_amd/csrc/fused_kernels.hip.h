@@ -261,6 +261,16 @@ __device__ __forceinline__ float fq_signed(float mag, unsigned sw) {
   return __uint_as_float(__float_as_uint(mag) | (sw & 0x80000000u));
 }
 
+// x << 1 as an add (v_add_u32 issues at the fast VALU rate, v_lshlrev_b32 does not; the
+// compiler turns x + x back into a shift, hence the asm)
+__device__ __forceinline__ unsigned fq_shl1(unsigned x) {
+  unsigned r;
+  asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// (a & b) | c in one v_bitop3_b32 (fast rate; v_and_or_b32 is not)
+#define FQ_ANDOR(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xEA)
+
 // LDS byte address of one of the two 16-bit entries packed in `packed`, by a volatile asm:
 // the unpacking cannot be hoisted out of the iteration loop (which would cost a register
 // per slot) and, unlike an empty asm that "modifies" the packed word, leaves the index
@@ -270,8 +280,9 @@ template <int HI, int SH>
 __device__ __forceinline__ lds_int *fq_slot_ptr(unsigned base, unsigned packed) {
   unsigned r;
   if (SH == 0) {
-    if (HI) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(base), "v"(packed));
-    else asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(base), "v"(packed));
+    // entries already hold absolute LDS byte addresses (base folded in when they were packed)
+    if (HI) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(r) : "v"(packed));
+    else asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(r) : "v"(packed));
   } else {
     if (HI) asm volatile("v_lshrrev_b32 %0, 14, %1\n\tv_and_b32 %0, 0x3fffc, %0" : "=&v"(r) : "v"(packed));
     else asm volatile("v_lshlrev_b32 %0, 2, %1\n\tv_and_b32 %0, 0x3fffc, %0" : "=&v"(r) : "v"(packed));
@@ -309,7 +320,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         lo = col[(size_t)(2 * k2) * B];
         hi = col[(size_t)(2 * k2 + 1) * B];
       }
-      idx[r][k2] = (lo << (2 - SH)) | ((hi << (2 - SH)) << 16);
+      if (SH == 0) { lo = lo * 4u + lbase; hi = hi * 4u + lbase; }   // absolute addresses (host: words*4 + static LDS < 64 Ki)
+      idx[r][k2] = lo | (hi << 16);
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) allm[r][w] = r < a.rounds ? a.maskT[((size_t)r * B + tid) * NW + w] : 0u;
@@ -363,13 +375,16 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       int bad = 0;
       // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
       // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
-      unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW];
+      unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW], orot[CPT][NW];
 #pragma unroll
       for (int r = 0; r < CPT; r++) {
         k1[r] = k2m[r] = 0xffffffffu;
         pp[r] = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) sg[r][w] = 0;
+        for (int w = 0; w < NW; w++) {
+          sg[r][w] = 0;
+          orot[r][w] = osg[r][w] << (32 - WB);   // old sign of the slot in turn: always bit 31
+        }
       }
       // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
       // reads in flight and CPT independent min chains
@@ -390,9 +405,10 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             const int k = kc + j;
             pp[r] ^= (unsigned)S[r][j];
             const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-            const float q = (float)S[r][j] - fq_signed(mo, osg[r][k / 32] << (32 - WB + (k % 32)));
+            const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
+            orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
             sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
-            const unsigned key = (__float_as_uint(q) & 0x7fffffffu) | (unsigned)k;
+            const unsigned key = FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
             k2m[r] = fq_med3u(k1[r], key, k2m[r]);
             k1[r] = min(k1[r], key);
           }
@@ -440,13 +456,17 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #pragma unroll
         for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]), "+v"(nsg[r][w]));
         const int m1o = (int)om1[r], m1n = (int)nm1[r];
+        unsigned nrot[NW], prot[NW];           // sign of the slot in turn in bit 31 (new / previous)
+#pragma unroll
+        for (int w = 0; w < NW; w++) { nrot[w] = nsg[r][w] << (32 - WB); prot[w] = osg[r][w] << (32 - WB); }
 #pragma unroll
         for (int k = 0; k < RM; k++) {
           lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
-          const int pos = WB - 1 - (k % 32);
-          const int sn = __builtin_amdgcn_sbfe((int)nsg[r][k / 32], pos, 1);   // 0 or -1
-          const int so = __builtin_amdgcn_sbfe((int)osg[r][k / 32], pos, 1);
-          const int delta = ((m1n ^ sn) - sn) - ((m1o ^ so) - so);
+          const float cn = __uint_as_float(FQ_ANDOR(nrot[k / 32], 0x80000000u, __float_as_uint(nm1[r])));
+          const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
+          nrot[k / 32] = fq_shl1(nrot[k / 32]);
+          prot[k / 32] = fq_shl1(prot[k / 32]);
+          const int delta = (int)(cn - co);
           __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
         }

@@ -684,8 +684,16 @@ struct FusedQ88Engine : Engine {
         return LDPC_ERR_UNSUPPORTED;
       }
       lds = (size_t)(sched.words + 4) * 4;
-      const bool small = (size_t)sched.words * 4 <= 65536;   // byte offsets fit 16 bits
-      kern = small ? pick_reg_r<0, 1024, 4>(rounds, rmax) : pick_reg_r<2, 1024, 4>(rounds, rmax);
+      // SH = 0 packs absolute 16-bit LDS byte addresses: the dynamic array starts after the
+      // kernel's static LDS (the scratch of __syncthreads_or), so that must fit as well
+      kern = pick_reg_r<0, 1024, 4>(rounds, rmax);
+      bool small = false;
+      if (kern) {
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
+        small = (size_t)(sched.words - 1) * 4 + fa.sharedSizeBytes <= 65535;
+      }
+      if (!small) kern = pick_reg_r<2, 1024, 4>(rounds, rmax);
       if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
       if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
       if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
