@@ -60,6 +60,33 @@ struct FusedArgs {
   int words, dummy_base, ndummy;
 };
 
+typedef void (*FusedKern)(FusedArgs);
+
+// The register-cached kernels are instantiated in fused_inst.hip, compiled in FQ_PARTS
+// parts; R2 (slot pairs per check) comes from this list: every value up to 16, then even.
+#define FQ_PARTS 4
+inline int fq_round_r2(int r2) {
+  if (r2 < 2) return 2;
+  if (r2 <= 16) return r2;
+  return r2 <= 32 ? (r2 + 1) / 2 * 2 : 0;
+}
+// shapes whose state fits the 128 VGPRs of a 16-wave workgroup without spilling (measured
+// from the compiler's register reports); others are not built and take the generic kernel
+constexpr bool fq_reg_shape_ok(int cpt, int r2) {
+  return cpt == 1 ? r2 <= 32 : cpt == 2 ? r2 <= 18 : cpt == 3 ? r2 <= 9 : false;
+}
+FusedKern fused_reg_lookup_part0(int cpt, int r2, int sh);
+FusedKern fused_reg_lookup_part1(int cpt, int r2, int sh);
+FusedKern fused_reg_lookup_part2(int cpt, int r2, int sh);
+FusedKern fused_reg_lookup_part3(int cpt, int r2, int sh);
+inline FusedKern fused_reg_lookup(int cpt, int r2, int sh) {
+  FusedKern k = fused_reg_lookup_part0(cpt, r2, sh);
+  if (!k) k = fused_reg_lookup_part1(cpt, r2, sh);
+  if (!k) k = fused_reg_lookup_part2(cpt, r2, sh);
+  if (!k) k = fused_reg_lookup_part3(cpt, r2, sh);
+  return k;
+}
+
 // timing experiments only (results wrong when non-zero): 1 no adds, 2 no reads, 4 no barriers
 // inside the iteration loop, 8 conflict-free read addresses, 16 conflict-free add addresses
 #ifndef LDPC_FUSED_ABLATE
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < CPT; r++) {
       om1[r] = om2[r] = nm1[r] = nm2[r] = 0.0f;
-      oarg[r] = narg[r] = 0xffu;
+      oarg[r] = narg[r] = 0u;                  // (om1 == om2 == 0: which slot it names is immaterial)
       ooff[r] = noff[r] = (unsigned)a.dummy_base * 4u;
 #pragma unroll
       for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w] = 0;
@@ -396,6 +423,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #pragma unroll
           for (int j = 0; j < CH; j++) {
             const int k = kc + j;
+            if (k >= RM) continue;               // (compile time: last chunk of an RM that CH does not divide)
             S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
           }
 #pragma unroll
@@ -403,6 +431,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #pragma unroll
           for (int r = 0; r < CPT; r++) {
             const int k = kc + j;
+            if (k >= RM) continue;
             pp[r] ^= (unsigned)S[r][j];
             const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
             const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
@@ -473,7 +502,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         {
           // slot oarg really carried +-min2 before; slot narg carries +-min2 now
           const int dmo = (int)om2[r] - m1o, dmn = (int)nm2[r] - m1n;
-          const unsigned ao = oarg[r] & (RM - 1), an = narg[r] & (RM - 1);
+          const unsigned ao = oarg[r], an = narg[r];   // < RM: a real slot always wins the minimum
           const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
           const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
           atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));

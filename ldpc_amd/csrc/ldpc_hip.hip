@@ -607,24 +607,6 @@ struct FusedQ88Engine : Engine {
     }
   }
 
-  template <int R2, int SH, int LB, int MINW>
-  static void (*pick_reg(int cpt))(FusedArgs) {
-    switch (cpt) {
-      case 1: return fused_q88_reg_kernel<1, R2, SH, LB, MINW>;
-      case 2: return fused_q88_reg_kernel<2, R2, SH, LB, MINW>;
-      case 3: return fused_q88_reg_kernel<3, R2, SH, LB, MINW>;
-      default: return nullptr;
-    }
-  }
-  template <int SH, int LB, int MINW>
-  static void (*pick_reg_r(int cpt, int rmax))(FusedArgs) {
-    if (rmax <= 8) return pick_reg<4, SH, LB, MINW>(cpt);
-    if (rmax <= 16) return pick_reg<8, SH, LB, MINW>(cpt);
-    if (rmax <= 32) return pick_reg<16, SH, LB, MINW>(cpt);
-    if (rmax <= 64) return pick_reg<32, SH, LB, MINW>(cpt);
-    return nullptr;
-  }
-
   int init(const ldpc_code &c, const ldpc_opts &o) override {
     opts = o;
     n = c.n; m = c.m; rmax = c.rmax;
@@ -639,7 +621,7 @@ struct FusedQ88Engine : Engine {
     // <= 16 waves per CU so that every wave gets 128 VGPRs); waves should own equal
     // numbers of checks.  Otherwise the generic kernel (indices re-read every iteration).
     const int need = (m + 63) / 64;
-    const int r2 = (rmax + 1) / 2;
+    const int r2 = fq_round_r2((rmax + 1) / 2);   // slot pairs per check the kernels come in
     int env_w = 0, env_g = 0, env_reg = 1;
     if (const char *e = getenv("LDPC_HIP_FUSED_WAVES")) env_w = atoi(e);
     if (const char *e = getenv("LDPC_HIP_FUSED_WG_PER_CU")) env_g = atoi(e);
@@ -653,7 +635,7 @@ struct FusedQ88Engine : Engine {
           if (env_w && W != env_w) continue;
           if (env_g && G != env_g) continue;
           const int r = (need + W - 1) / W;
-          if (r > 3 || r * r2 > 64) continue;
+          if (!fq_reg_shape_ok(r, r2)) continue;
           const double score = (double)need / ((double)r * W) + 0.01 * W * G + 0.005 * G;
           if (score > best) { best = score; bestW = W; bestG = G; }
         }
@@ -676,7 +658,7 @@ struct FusedQ88Engine : Engine {
     rounds = (m + block - 1) / block;
     int rc;
     if (use_reg) {
-      const int RM = rmax <= 8 ? 8 : rmax <= 16 ? 16 : rmax <= 32 ? 32 : 64;
+      const int RM = 2 * r2;
       int optimise = 1;
       if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
       if (ldpc_build_lds_schedule(c, block, RM, FQ_NDUMMY, optimise != 0, sched)) {
@@ -686,14 +668,14 @@ struct FusedQ88Engine : Engine {
       lds = (size_t)(sched.words + 4) * 4;
       // SH = 0 packs absolute 16-bit LDS byte addresses: the dynamic array starts after the
       // kernel's static LDS (the scratch of __syncthreads_or), so that must fit as well
-      kern = pick_reg_r<0, 1024, 4>(rounds, rmax);
+      kern = fused_reg_lookup(rounds, r2, 0);
       bool small = false;
       if (kern) {
         hipFuncAttributes fa;
         HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
         small = (size_t)(sched.words - 1) * 4 + fa.sharedSizeBytes <= 65535;
       }
-      if (!small) kern = pick_reg_r<2, 1024, 4>(rounds, rmax);
+      if (!small) kern = fused_reg_lookup(rounds, r2, 2);
       if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
       if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
       if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
@@ -837,7 +819,7 @@ extern "C" void ldpc_decoder_free(ldpc_decoder *d) {
 
 extern "C" int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, int64_t *stats) {
   if (!c || !stats || block <= 0 || block % 64 || c->rmax > 64) return LDPC_ERR_ARG;
-  const int RM = c->rmax <= 8 ? 8 : c->rmax <= 16 ? 16 : c->rmax <= 32 ? 32 : 64;
+  const int RM = 2 * ldpc::fq_round_r2((c->rmax + 1) / 2);
   LdsSchedule s;
   if (ldpc_build_lds_schedule(*c, block, RM, FQ_NDUMMY, optimise != 0, s)) return LDPC_ERR_UNSUPPORTED;
   stats[0] = s.conflicts; stats[1] = s.accesses; stats[2] = s.words; stats[3] = s.RM;

@@ -226,5 +226,11 @@ int ldpc_build_lds_schedule(const ldpc_code &c, int block, int RM, int ndummy, b
       out.dcT[(size_t)(j / block) * block + j % block] = (uint8_t)std::min(255, c.row_ptr[j + 1] - c.row_ptr[j]);
     }
   }
+  if (optimise && out.conflicts > 0) {
+    // structured (e.g. quasi-cyclic) codes can be conflict free just as they stand, and a slot
+    // count with no slack leaves the colouring no room: keep whichever placement is better
+    LdsSchedule nat;
+    if (ldpc_build_lds_schedule(c, block, RM, ndummy, false, nat) == 0 && nat.conflicts < out.conflicts) out = nat;
+  }
   return 0;
 }

