@@ -61,6 +61,8 @@ struct FusedArgs {
 };
 
 typedef void (*FusedKern)(FusedArgs);
+typedef unsigned fq_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned fq_u2 __attribute__((ext_vector_type(2)));
 
 // The register-cached kernels are instantiated in fused_inst.hip, compiled in FQ_PARTS
 // parts; R2 (slot pairs per check) comes from this list: every value up to 16, then even.
@@ -354,15 +356,34 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     for (int w = 0; w < NW; w++) allm[r][w] = r < a.rounds ? a.maskT[((size_t)r * B + tid) * NW + w] : 0u;
   }
 
+  // 8 variables per thread and step on the way in (int16 LLRs) and out (bits): needs
+  // 16-byte aligned frames / 8-byte aligned bit rows
+  const bool vec_in = a.dt == 2 && (a.n & 7) == 0 && ((size_t)a.llr & 15) == 0;
+  const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const fq_u4 *pos8 = (const fq_u4 *)a.pos;
+
+  if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
+  __syncthreads();
   for (;;) {
-    __syncthreads();
-    if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
-    __syncthreads();
     const int frame = *frame_slot;
     if (frame >= a.nframes) break;
+    // the next frame's number is fetched now and published at the end of this frame: the
+    // round trip of the device atomic hides under the decoding
+    int next_frame = 0;
+    if (tid == 0) next_frame = atomicAdd(a.counter, 1);
     {
       const size_t base = (size_t)frame * a.n;
-      if (a.dt == 2) {
+      if (vec_in) {
+        const fq_u4 *p8 = (const fq_u4 *)((const short *)a.llr + base);
+        for (int i = tid; i < (a.n >> 3); i += B) {
+          const fq_u4 v = __builtin_nontemporal_load(p8 + i);
+          const fq_u4 w = pos8[i];
+          fsum[w.x & 0xffffu] = (int)(short)(v.x & 0xffffu); fsum[w.x >> 16] = (int)v.x >> 16;
+          fsum[w.y & 0xffffu] = (int)(short)(v.y & 0xffffu); fsum[w.y >> 16] = (int)v.y >> 16;
+          fsum[w.z & 0xffffu] = (int)(short)(v.z & 0xffffu); fsum[w.z >> 16] = (int)v.z >> 16;
+          fsum[w.w & 0xffffu] = (int)(short)(v.w & 0xffffu); fsum[w.w >> 16] = (int)v.w >> 16;
+        }
+      } else if (a.dt == 2) {
         const short *p = (const short *)a.llr + base;
         for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = p[i];
       } else if (a.dt == 3) {
@@ -515,7 +536,18 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       if (!(LDPC_FUSED_ABLATE & 4)) __syncthreads();
     }
 
-    if (a.bits) {
+    if (vec_out) {
+      fq_u2 *o8 = (fq_u2 *)(a.bits + (size_t)frame * a.n);
+      for (int i = tid; i < (a.n >> 3); i += B) {
+        const fq_u4 w = pos8[i];
+        fq_u2 b;
+        b.x = ((unsigned)fsum[w.x & 0xffffu] >> 31) | (((unsigned)fsum[w.x >> 16] >> 31) << 8) |
+              (((unsigned)fsum[w.y & 0xffffu] >> 31) << 16) | (((unsigned)fsum[w.y >> 16] >> 31) << 24);
+        b.y = ((unsigned)fsum[w.z & 0xffffu] >> 31) | (((unsigned)fsum[w.z >> 16] >> 31) << 8) |
+              (((unsigned)fsum[w.w & 0xffffu] >> 31) << 16) | (((unsigned)fsum[w.w >> 16] >> 31) << 24);
+        __builtin_nontemporal_store(b, o8 + i);
+      }
+    } else if (a.bits) {
       uint8_t *o = a.bits + (size_t)frame * a.n;
       for (int i = tid; i < a.n; i += B) o[i] = fsum[a.pos[i]] < 0;
     }
@@ -536,6 +568,13 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       if (a.iters) a.iters[frame] = it_done;
       if (a.status) a.status[frame] = ok ? 0 : 1;
     }
+    __syncthreads();                           // everyone has read this frame's number and its sums
+    if (tid == 0) *frame_slot = next_frame;
+    // The barrier that publishes the number sits here, in line after the write, not at the
+    // loop head: there the compiler (ROCm 7.2) dropped the s_waitcnt between this ds_write
+    // and the s_barrier across the back edge, and waves read the previous number.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 }
 
