@@ -356,6 +356,9 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     for (int w = 0; w < NW; w++) allm[r][w] = r < a.rounds ? a.maskT[((size_t)r * B + tid) * NW + w] : 0u;
   }
 
+  // does this wavefront own any check of the last round?  (wave-uniform)
+  const bool wave_full = __ballot(dc[CPT - 1] != 0) != 0;
+
   // 8 variables per thread and step on the way in (int16 LLRs) and out (bits): needs
   // 16-byte aligned frames / 8-byte aligned bit rows
   const bool vec_in = a.dt == 2 && (a.n & 7) == 0 && ((size_t)a.llr & 15) == 0;
@@ -421,76 +424,84 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     int it_done = a.max_iter, ok = 0;
     for (int t = 1; t <= a.max_iter + 1; t++) {
       int bad = 0;
-      // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
-      // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
-      unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW], orot[CPT][NW];
+      // Phase A for the first NA of the thread's checks.  NA is CPT except in wavefronts whose
+      // last round holds no check at all (the rounds fill up in order, so those have exactly
+      // CPT - 1): they run the shorter instruction stream instead of walking dummy slots.
+      auto phase_a = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+        // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
+        // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
+        unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW], orot[CPT][NW];
 #pragma unroll
-      for (int r = 0; r < CPT; r++) {
-        k1[r] = k2m[r] = 0xffffffffu;
-        pp[r] = 0;
+        for (int r = 0; r < NA; r++) {
+          k1[r] = k2m[r] = 0xffffffffu;
+          pp[r] = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-          sg[r][w] = 0;
-          orot[r][w] = osg[r][w] << (32 - WB);   // old sign of the slot in turn: always bit 31
-        }
-      }
-      // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
-      // reads in flight and CPT independent min chains
-#pragma unroll
-      for (int kc = 0; kc < RM; kc += CH) {
-        int S[CPT][CH];
-#pragma unroll
-        for (int r = 0; r < CPT; r++)
-#pragma unroll
-          for (int j = 0; j < CH; j++) {
-            const int k = kc + j;
-            if (k >= RM) continue;               // (compile time: last chunk of an RM that CH does not divide)
-            S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
+          for (int w = 0; w < NW; w++) {
+            sg[r][w] = 0;
+            orot[r][w] = osg[r][w] << (32 - WB);   // old sign of the slot in turn: always bit 31
           }
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-#pragma unroll
-          for (int r = 0; r < CPT; r++) {
-            const int k = kc + j;
-            if (k >= RM) continue;
-            pp[r] ^= (unsigned)S[r][j];
-            const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-            const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
-            orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
-            sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
-            const unsigned key = FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
-            k2m[r] = fq_med3u(k1[r], key, k2m[r]);
-            k1[r] = min(k1[r], key);
-          }
-      }
-#pragma unroll
-      for (int r = 0; r < CPT; r++) {
-        const unsigned p = pp[r] >> 31;
-        par[r] = (int)p;
-        bad |= (int)p ^ sbit[r];
-        unsigned tot = (unsigned)sbit[r];
-#pragma unroll
-        for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[r][w]);
-        nm1[r] = fq_finish_minf(__uint_as_float(k1[r] & ~KM));
-        nm2[r] = fq_finish_minf(__uint_as_float(k2m[r] & ~KM));
-        narg[r] = k1[r] & KM;
-        // where slot narg's variable lives (needed by phase B's fix-up; the load hides under the barrier)
-        {
-          // opaque pointer: keeps the compiler from relating this load to the index registers
-          const uint16_t *ct = a.colT;
-          asm volatile("" : "+s"(ct));
-          const int rr = r < a.rounds ? r : a.rounds - 1;
-          noff[r] = (unsigned)ct[((size_t)rr * RM + narg[r]) * B + tid] * 4u;
         }
-        // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
+        // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
+        // reads in flight and CPT independent min chains
 #pragma unroll
-        for (int w = 0; w < NW; w++) nsg[r][w] = (tot & 1) ? (sg[r][w] ^ allm[r][w]) : sg[r][w];
-        // materialise the compressed state now: left alone the compiler carries the 2*R2
-        // per-slot values of this check across the barrier instead (register spills)
-        asm volatile("" : "+v"(nm1[r]), "+v"(nm2[r]), "+v"(narg[r]));
+        for (int kc = 0; kc < RM; kc += CH) {
+          int S[CPT][CH];
 #pragma unroll
-        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nsg[r][w]));
-      }
+          for (int r = 0; r < NA; r++)
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+              const int k = kc + j;
+              if (k >= RM) continue;               // (compile time: last chunk of an RM that CH does not divide)
+              S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
+            }
+#pragma unroll
+          for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int r = 0; r < NA; r++) {
+              const int k = kc + j;
+              if (k >= RM) continue;
+              pp[r] ^= (unsigned)S[r][j];
+              const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
+              const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
+              orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
+              sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
+              const unsigned key = FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
+              k2m[r] = fq_med3u(k1[r], key, k2m[r]);
+              k1[r] = min(k1[r], key);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          const unsigned p = pp[r] >> 31;
+          par[r] = (int)p;
+          bad |= (int)p ^ sbit[r];
+          unsigned tot = (unsigned)sbit[r];
+#pragma unroll
+          for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[r][w]);
+          nm1[r] = fq_finish_minf(__uint_as_float(k1[r] & ~KM));
+          nm2[r] = fq_finish_minf(__uint_as_float(k2m[r] & ~KM));
+          narg[r] = k1[r] & KM;
+          // where slot narg's variable lives (needed by phase B's fix-up; the load hides under the barrier)
+          {
+            // opaque pointer: keeps the compiler from relating this load to the index registers
+            const uint16_t *ct = a.colT;
+            asm volatile("" : "+s"(ct));
+            const int rr = r < a.rounds ? r : a.rounds - 1;
+            noff[r] = (unsigned)ct[((size_t)rr * RM + narg[r]) * B + tid] * 4u;
+          }
+          // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
+#pragma unroll
+          for (int w = 0; w < NW; w++) nsg[r][w] = (tot & 1) ? (sg[r][w] ^ allm[r][w]) : sg[r][w];
+          // materialise the compressed state now: left alone the compiler carries the 2*R2
+          // per-slot values of this check across the barrier instead (register spills)
+          asm volatile("" : "+v"(nm1[r]), "+v"(nm2[r]), "+v"(narg[r]));
+#pragma unroll
+          for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nsg[r][w]));
+        }
+      };
+      if (wave_full) phase_a(std::integral_constant<int, CPT>{});
+      else phase_a(std::integral_constant<int, CPT - 1>{});
       const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : __syncthreads_or(bad);
       if (!any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
@@ -499,40 +510,45 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       // slot of min1 itself, where it is +-min2.  The slot loop treats every slot as
       // "+-min1" (integer arithmetic on sign masks, no per-slot selects) and the two
       // exceptional slots are put right afterwards by one extra add each.
+      auto phase_b = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
 #pragma unroll
-      for (int r = 0; r < CPT; r++) {
-        // (re)derive everything from the compressed state here, not before the barrier
-        asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]));
+        for (int r = 0; r < NA; r++) {
+          // (re)derive everything from the compressed state here, not before the barrier
+          asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]));
 #pragma unroll
-        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]), "+v"(nsg[r][w]));
-        const int m1o = (int)om1[r], m1n = (int)nm1[r];
-        unsigned nrot[NW], prot[NW];           // sign of the slot in turn in bit 31 (new / previous)
+          for (int w = 0; w < NW; w++) asm volatile("" : "+v"(osg[r][w]), "+v"(nsg[r][w]));
+          const int m1o = (int)om1[r], m1n = (int)nm1[r];
+          unsigned nrot[NW], prot[NW];           // sign of the slot in turn in bit 31 (new / previous)
 #pragma unroll
-        for (int w = 0; w < NW; w++) { nrot[w] = nsg[r][w] << (32 - WB); prot[w] = osg[r][w] << (32 - WB); }
+          for (int w = 0; w < NW; w++) { nrot[w] = nsg[r][w] << (32 - WB); prot[w] = osg[r][w] << (32 - WB); }
 #pragma unroll
-        for (int k = 0; k < RM; k++) {
-          lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
-          const float cn = __uint_as_float(FQ_ANDOR(nrot[k / 32], 0x80000000u, __float_as_uint(nm1[r])));
-          const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
-          nrot[k / 32] = fq_shl1(nrot[k / 32]);
-          prot[k / 32] = fq_shl1(prot[k / 32]);
-          const int delta = (int)(cn - co);
-          __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
+          for (int k = 0; k < RM; k++) {
+            lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
+            const float cn = __uint_as_float(FQ_ANDOR(nrot[k / 32], 0x80000000u, __float_as_uint(nm1[r])));
+            const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
+            nrot[k / 32] = fq_shl1(nrot[k / 32]);
+            prot[k / 32] = fq_shl1(prot[k / 32]);
+            const int delta = (int)(cn - co);
+            __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
+          }
+          {
+            // slot oarg really carried +-min2 before; slot narg carries +-min2 now
+            const int dmo = (int)om2[r] - m1o, dmn = (int)nm2[r] - m1n;
+            const unsigned ao = oarg[r], an = narg[r];   // < RM: a real slot always wins the minimum
+            const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
+            const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
+            atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
+            atomicAdd((int *)(lds + noff[r]), (dmn ^ sn) - sn);
+          }
+          om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
+#pragma unroll
+          for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w];
         }
-        {
-          // slot oarg really carried +-min2 before; slot narg carries +-min2 now
-          const int dmo = (int)om2[r] - m1o, dmn = (int)nm2[r] - m1n;
-          const unsigned ao = oarg[r], an = narg[r];   // < RM: a real slot always wins the minimum
-          const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
-          const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
-          atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
-          atomicAdd((int *)(lds + noff[r]), (dmn ^ sn) - sn);
-        }
-        om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
-#pragma unroll
-        for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w];
-      }
+      };
+      if (wave_full) phase_b(std::integral_constant<int, CPT>{});
+      else phase_b(std::integral_constant<int, CPT - 1>{});
       if (!(LDPC_FUSED_ABLATE & 4)) __syncthreads();
     }
 
