@@ -75,7 +75,7 @@ inline int fq_round_r2(int r2) {
 // shapes whose state fits the 128 VGPRs of a 16-wave workgroup without spilling (measured
 // from the compiler's register reports); others are not built and take the generic kernel
 constexpr bool fq_reg_shape_ok(int cpt, int r2) {
-  return cpt == 1 ? r2 <= 32 : cpt == 2 ? r2 <= 18 : cpt == 3 ? r2 <= 9 : false;
+  return cpt == 1 ? r2 <= 32 : cpt == 2 ? r2 <= 16 : cpt == 3 ? r2 <= 9 : false;
 }
 FusedKern fused_reg_lookup_part0(int cpt, int r2, int sh);
 FusedKern fused_reg_lookup_part1(int cpt, int r2, int sh);

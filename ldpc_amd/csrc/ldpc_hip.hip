@@ -636,7 +636,13 @@ struct FusedQ88Engine : Engine {
           if (env_g && G != env_g) continue;
           const int r = (need + W - 1) / W;
           if (!fq_reg_shape_ok(r, r2)) continue;
-          const double score = (double)need / ((double)r * W) + 0.01 * W * G + 0.005 * G;
+          // wavefront w owns r groups of 64 checks if w < full, else r - 1 (and runs the shorter
+          // instruction stream); wavefronts go to the 4 SIMDs in turn, the busiest SIMD sets the pace
+          const int full = need - (r - 1) * W;
+          int load[4] = {0, 0, 0, 0};
+          for (int w = 0; w < W; w++) load[w & 3] += w < full ? r : r - 1;
+          const int worst = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+          const double score = (double)need / (4.0 * worst) + 0.002 * W * G + 0.001 * G;
           if (score > best) { best = score; bestW = W; bestG = G; }
         }
       use_reg = bestW > 0;
