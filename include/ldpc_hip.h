@@ -190,6 +190,57 @@ int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, in
 int ldpc_decoder_profile(ldpc_decoder *d, int enable);
 int ldpc_decoder_profile_read(ldpc_decoder *d, double *ms, int32_t *launches);
 
+/* ------------------------------------------------ Monte-Carlo loop on the device
+ * The trial loop of the reference's *_cw_noise_gen harnesses
+ * (test_code_min_sum_B.c:307-323, test_code_min_sum_B_fixed.c:415-434,
+ * test_code_B_float.c:299-316, test_code_no_mex_B.c:345-372) with every step on
+ * the GPU: source word (x[j] = rand() & 1), s = enc(x) (:69-79), channel and LLRs
+ * (bsc(), :41-67), dec(), and the classification (dec()'s return value, HamDist
+ * :81-90).  Nothing but eight counters crosses PCIe.
+ *
+ * Random numbers are counter-based: (seed, global frame index) fixes a frame's
+ * source word and noise whatever the batch size, the number of GPUs or the order
+ * of the passes -- shard a run by giving each rank its own first_frame. */
+typedef enum ldpc_channel {
+  LDPC_CH_BSC_EXACT = 0, /* the reference's bsc(): exactly round(n p) distinct flips, LLR
+                            magnitude log((1-p')/p') with p' = flips / n                   */
+  LDPC_CH_BSC_IID   = 1, /* independent flips with probability p                           */
+  LDPC_CH_AWGN      = 2  /* BPSK 1-2x plus N(0, sigma^2); LLR = 2 y / sigma^2              */
+} ldpc_channel;
+typedef enum ldpc_source {
+  LDPC_SRC_RANDOM = 0,   /* a fresh random word per frame (the mex harnesses)              */
+  LDPC_SRC_FIXED  = 1,   /* one random word for the whole run (test_code_no_mex_B.c:339-343) */
+  LDPC_SRC_ZERO   = 2    /* the all-zero word                                              */
+} ldpc_source;
+typedef struct ldpc_mc_opts {
+  int32_t  channel;      /* ldpc_channel                                                   */
+  int32_t  source;       /* ldpc_source                                                    */
+  int32_t  llr_dtype;    /* what the decoder is fed: F64 / F32 values, I16 = Q8.8 raw through
+                            float_to_fix() (_fixed.c:117-120), I32 = Q8.14 raw through
+                            float2fix() (test_code_B.c:122-125)                            */
+  int32_t  max_iter;     /* dec()'s loop_max                                               */
+  double   param;        /* BSC: p;  AWGN: sigma                                           */
+  uint64_t seed;
+  uint64_t first_frame;  /* global index of the run's first frame                          */
+  int32_t  reserved[8];
+} ldpc_mc_opts;
+typedef struct ldpc_mc ldpc_mc;
+
+/* Buffers for passes of ldpc_decoder_max_frames(d) frames on `device` (the
+ * decoder's device).  The code and the decoder must outlive the context. */
+int  ldpc_mc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_mc **out);
+void ldpc_mc_free(ldpc_mc *mc);
+/* Runs nframes trials; counters[8] = {frames, not converged (errors[0]),
+ * converged to a word != x (errors[1]), bit errors over all frames, iterations
+ * executed, frames with any bit error, bit errors of converged frames, 0}. */
+int  ldpc_mc_run(ldpc_mc *mc, const ldpc_mc_opts *o, int64_t nframes, uint64_t *counters);
+/* Generation only, for inspection: frames first_frame .. +nframes (at most one
+ * pass) copied to host x[nframes][n], llr[nframes][n] of llr_dtype, synd[nframes][m];
+ * any pointer may be NULL. */
+int  ldpc_mc_generate(ldpc_mc *mc, const ldpc_mc_opts *o, int nframes, uint8_t *x, void *llr, uint8_t *synd);
+/* The last pass of ldpc_mc_run copied to the host (its first nframes frames). */
+int  ldpc_mc_last_pass(ldpc_mc *mc, int nframes, uint8_t *x, uint8_t *bits, int32_t *status, int32_t *iters);
+
 /* ------------------------------------------- reference-shaped entry points
  * Same names, argument order and meaning as the reference's C harness
  * functions; `errors` is the caller's double[2] = {not converged, converged to

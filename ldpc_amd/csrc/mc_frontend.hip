@@ -1,0 +1,356 @@
+// mc_frontend.hip -- the Monte-Carlo loop around dec(), on the device.
+//
+// The reference's *_cw_noise_gen harnesses (test_code_min_sum_B.c:288-329,
+// test_code_min_sum_B_fixed.c:396-440, test_code_B_float.c:280-325,
+// test_code_no_mex_B.c:321-381) run, per trial:  x = random bits, s = enc(x)
+// (:69-79), y/q0 = bsc(x, p) (:41-67), dec(q0, s), then classify: not converged
+// -> errors[0]++, converged to a word != x -> errors[1]++ (HamDist, :81-90).
+// Here a batch of trials is one pass of four kernels that never leaves HBM:
+//
+//   mc_gen_kernel      source word, channel, LLRs in the decoder's input type,
+//                      syndrome.  One workgroup builds FPW frames: the frames' x
+//                      and error patterns live in LDS as bitmaps, the outputs are
+//                      written frame-major with coalesced rows.
+//   (decoder)          ldpc_decode_batch_device() on those buffers
+//   mc_classify_kernel Hamming distance of every decoded frame to its x and the
+//                      status, reduced into eight 64-bit counters by atomics.
+//
+// Random numbers: the reference seeds libc rand() from time(NULL), so its streams are
+// not reproducible by design.  Here every (seed, global frame index, stream) names a
+// counter-based splitmix64 sequence -- draw i = mix64(key + (i+1)*GOLDEN) -- so a
+// frame's data does not depend on batch size, GPU count or launch order.  The tests hold a
+// numpy restatement of this file's generators.
+//
+// Channels: BSC_EXACT is the reference's bsc(): exactly round(n p) distinct positions,
+// found by rejection on uniform draws, LLR magnitude log((1-p')/p') with p' = flips/n.
+// BSC_IID flips every bit independently with probability p (LLR magnitude from p).
+// AWGN: BPSK, y = (1 - 2x) + sigma N(0,1), LLR = 2 y / sigma^2 (Box-Muller).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace {
+
+constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// stream: 0 source bits, 1 channel
+__host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t frame, uint64_t stream) {
+  return mix64(seed ^ mix64(frame * 4 + stream + GOLDEN));
+}
+__host__ __device__ inline uint64_t draw(uint64_t key, uint64_t i) { return mix64(key + (i + 1) * GOLDEN); }
+
+struct McArgs {
+  int n, m, nw;               // nw = ceil(n / 32) bitmap words per frame
+  int nframes, fpw;           // frames in this pass, frames per workgroup
+  int channel, source, dt;
+  int flips;                  // BSC_EXACT: round(n p)
+  double llr_mag;             // BSC: log((1-p)/p)
+  double p, sigma;
+  uint64_t seed, first_frame;
+  const int32_t *row_ptr, *col_idx;
+  uint8_t *x;                 // [nframes][n]
+  void *llr;                  // [nframes][n] of dt
+  uint8_t *synd;              // [nframes][m]
+};
+
+// float_to_fix() of test_code_min_sum_B_fixed.c:43-53, raw (value * 256)
+__device__ inline int q88_raw(double v) {
+  double r = round(v * 256.0);
+  if (r > 127.0 * 256.0) r = 127.0 * 256.0;
+  if (r < -128.0 * 256.0) r = -128.0 * 256.0;
+  return (int)r;
+}
+// float2fix() of test_code_B.c:36-43
+__device__ inline int q14_raw(double x) {
+  if (x >= 0) return (int)(x * 16384.0 + 0.5);
+  return -(int)((-x) * 16384.0 + 0.5);
+}
+__device__ inline void store_llr(void *base, int dt, size_t at, double d) {
+  switch (dt) {
+    case LDPC_DT_F64: ((double *)base)[at] = d; break;
+    case LDPC_DT_F32: ((float *)base)[at] = (float)d; break;
+    case LDPC_DT_I16: ((int16_t *)base)[at] = (int16_t)q88_raw(d); break;
+    default: ((int32_t *)base)[at] = q14_raw(d); break;
+  }
+}
+
+__global__ __launch_bounds__(256) void mc_gen_kernel(McArgs a) {
+  extern __shared__ uint32_t bm[];            // [fpw][2][nw]: x bitmap, error bitmap
+  const int tid = threadIdx.x, B = blockDim.x;
+  const int f0 = blockIdx.x * a.fpw;
+  const int nf = min(a.fpw, a.nframes - f0);
+  if (nf <= 0) return;
+  const int nw = a.nw;
+  const uint32_t tailmask = (a.n & 31) ? ((1u << (a.n & 31)) - 1u) : 0xffffffffu;
+
+  // ---- source words (x[j] = rand() & 1, :308-311) and cleared error bitmaps
+  for (int t = tid; t < nf * nw; t += B) {
+    const int f = t / nw, w = t % nw;
+    uint32_t xb = 0;
+    if (a.source != 2) {
+      const uint64_t fr = a.source == 1 ? ~0ull : a.first_frame + (uint64_t)(f0 + f);
+      xb = (uint32_t)draw(stream_key(a.seed, fr, 0), (uint64_t)w);
+      if (w == nw - 1) xb &= tailmask;
+    }
+    bm[(f * 2 + 0) * nw + w] = xb;
+    bm[(f * 2 + 1) * nw + w] = 0;
+  }
+  __syncthreads();
+
+  // ---- channel error patterns
+  if (a.channel == 0) {
+    // bsc(), :41-67: draw positions until `flips` distinct ones are marked; one thread per
+    // frame walks its own bitmap, so the pattern depends on the frame's stream alone
+    if (tid < nf) {
+      uint32_t *eb = bm + (tid * 2 + 1) * nw;
+      const uint64_t key = stream_key(a.seed, a.first_frame + (uint64_t)(f0 + tid), 1);
+      int num = 0;
+      for (uint64_t i = 0; num < a.flips; i++) {
+        const uint32_t pos = (uint32_t)(((draw(key, i) >> 32) * (uint64_t)a.n) >> 32);
+        const uint32_t bit = 1u << (pos & 31);
+        const uint32_t w = eb[pos >> 5];
+        if (w & bit) continue;
+        eb[pos >> 5] = w | bit;
+        num++;
+      }
+    }
+  } else if (a.channel == 1) {
+    const uint64_t thr = a.p >= 1.0 ? ~0ull : (uint64_t)(a.p * 18446744073709551616.0);
+    for (int t = tid; t < nf * nw; t += B) {
+      const int f = t / nw, w = t % nw;
+      const uint64_t key = stream_key(a.seed, a.first_frame + (uint64_t)(f0 + f), 1);
+      uint32_t e = 0;
+      for (int b = 0; b < 32; b++)
+        if (draw(key, (uint64_t)w * 32 + b) < thr) e |= 1u << b;
+      if (w == nw - 1) e &= tailmask;
+      bm[(f * 2 + 1) * nw + w] = e;
+    }
+  }
+  __syncthreads();
+
+  // ---- x, LLRs (frame-major rows, coalesced)
+  for (int f = 0; f < nf; f++) {
+    const size_t row = (size_t)(f0 + f) * a.n;
+    const uint32_t *xb = bm + (f * 2 + 0) * nw, *eb = bm + (f * 2 + 1) * nw;
+    const uint64_t key = stream_key(a.seed, a.first_frame + (uint64_t)(f0 + f), 1);
+    for (int i = tid; i < a.n; i += B) {
+      const int xi = (xb[i >> 5] >> (i & 31)) & 1;
+      a.x[row + i] = (uint8_t)xi;
+      double d;
+      if (a.channel == 2) {
+        const double u1 = (double)((draw(key, 2 * (uint64_t)i) >> 11) + 1) * (1.0 / 9007199254740992.0);
+        const double u2 = (double)(draw(key, 2 * (uint64_t)i + 1) >> 11) * (1.0 / 9007199254740992.0);
+        const double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+        const double y = (double)(1 - 2 * xi) + a.sigma * g;
+        d = 2.0 * y / (a.sigma * a.sigma);
+      } else {
+        const int yi = xi ^ (int)((eb[i >> 5] >> (i & 31)) & 1);
+        d = (double)(1 - 2 * yi) * a.llr_mag;   // q0[i] = (1 - 2 y[i]) log((1-p)/p), :63-66
+      }
+      store_llr(a.llr, a.dt, row + i, d);
+    }
+  }
+
+  // ---- syndrome, enc() :69-79
+  for (int t = tid; t < nf * a.m; t += B) {
+    const int f = t / a.m, j = t % a.m;
+    const uint32_t *xb = bm + (f * 2 + 0) * nw;
+    uint32_t k = 0;
+    for (int e = a.row_ptr[j]; e < a.row_ptr[j + 1]; e++) {
+      const int v = a.col_idx[e];
+      k ^= xb[v >> 5] >> (v & 31);
+    }
+    a.synd[(size_t)(f0 + f) * a.m + j] = (uint8_t)(k & 1);
+  }
+}
+
+// counters: 0 frames, 1 not converged, 2 converged to a word != x, 3 bit errors (all
+// frames), 4 iterations, 5 frames with any bit error, 6 bit errors of converged frames
+__global__ __launch_bounds__(256) void mc_classify_kernel(int n, int nframes, const uint8_t *x, const uint8_t *bits,
+                                                          const int32_t *status, const int32_t *iters,
+                                                          unsigned long long *counters) {
+  __shared__ int red[4];
+  const int f = blockIdx.x;
+  if (f >= nframes) return;
+  int diff = 0;
+  const uint8_t *xr = x + (size_t)f * n, *br = bits + (size_t)f * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) diff += (xr[i] ^ br[i]) & 1;
+  for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = diff;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += red[w];
+    const int st = status[f];
+    atomicAdd(&counters[0], 1ull);
+    if (st) atomicAdd(&counters[1], 1ull);
+    else if (tot) atomicAdd(&counters[2], 1ull);
+    if (tot) {
+      atomicAdd(&counters[3], (unsigned long long)tot);
+      atomicAdd(&counters[5], 1ull);
+      if (!st) atomicAdd(&counters[6], (unsigned long long)tot);
+    }
+    atomicAdd(&counters[4], (unsigned long long)iters[f]);
+  }
+}
+
+size_t dt_size(int dt) { return dt == LDPC_DT_F64 ? 8 : dt == LDPC_DT_I16 ? 2 : 4; }
+
+}  // namespace
+
+struct ldpc_mc {
+  const ldpc_code *code = nullptr;
+  ldpc_decoder *dec = nullptr;
+  int device = 0, max_frames = 0;
+  DevBuf d_row_ptr, d_col_idx, d_x, d_llr, d_synd, d_bits, d_iters, d_status, d_counters;
+};
+
+extern "C" int ldpc_mc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_mc **out) {
+  if (!c || !d || !out) return LDPC_ERR_ARG;
+  if (c->q != 2) {
+    ldpc_set_error("the device Monte-Carlo front-end is for binary codes");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  HIPCHK(hipSetDevice(device));
+  ldpc_mc *mc = new ldpc_mc;
+  mc->code = c; mc->dec = d; mc->device = device;
+  mc->max_frames = ldpc_decoder_max_frames(d);
+  const size_t F = (size_t)mc->max_frames, n = (size_t)c->n, m = (size_t)c->m;
+  int rc;
+  if ((rc = mc->d_row_ptr.ensure((m + 1) * 4)) || (rc = mc->d_col_idx.ensure((size_t)c->E() * 4 + 4)) ||
+      (rc = mc->d_x.ensure(F * n)) || (rc = mc->d_llr.ensure(F * n * 8)) || (rc = mc->d_synd.ensure(F * m + 4)) ||
+      (rc = mc->d_bits.ensure(F * n)) || (rc = mc->d_iters.ensure(F * 4)) || (rc = mc->d_status.ensure(F * 4)) ||
+      (rc = mc->d_counters.ensure(64))) {
+    delete mc;
+    return rc;
+  }
+  hipError_t e = hipMemcpy(mc->d_row_ptr.p, c->row_ptr.data(), (m + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(mc->d_col_idx.p, c->col_idx.data(), (size_t)c->E() * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ldpc_set_error(std::string("ldpc_mc_create: ") + hipGetErrorString(e));
+    delete mc;
+    return LDPC_ERR_HIP;
+  }
+  *out = mc;
+  return LDPC_OK;
+}
+
+extern "C" void ldpc_mc_free(ldpc_mc *mc) {
+  if (!mc) return;
+  (void)hipSetDevice(mc->device);
+  delete mc;
+}
+
+static int mc_check(const ldpc_mc *mc, const ldpc_mc_opts *o) {
+  if (!mc || !o) return LDPC_ERR_ARG;
+  if (o->channel < 0 || o->channel > 2 || o->source < 0 || o->source > 2 || o->llr_dtype < 0 || o->llr_dtype > 3 ||
+      o->max_iter < 0) {
+    ldpc_set_error("ldpc_mc: bad channel / source / dtype / max_iter");
+    return LDPC_ERR_ARG;
+  }
+  if (o->channel == LDPC_CH_AWGN ? !(o->param > 0) : !(o->param > 0 && o->param < 1)) {
+    ldpc_set_error("ldpc_mc: channel parameter out of range (BSC: 0 < p < 1, AWGN: sigma > 0)");
+    return LDPC_ERR_ARG;
+  }
+  return LDPC_OK;
+}
+
+// one pass: frames [first, first + nf) into the context's buffers
+static int mc_generate_pass(ldpc_mc *mc, const ldpc_mc_opts *o, uint64_t first, int nf, hipStream_t st) {
+  const ldpc_code &c = *mc->code;
+  McArgs a;
+  memset(&a, 0, sizeof a);
+  a.n = c.n; a.m = c.m; a.nw = (c.n + 31) / 32;
+  a.nframes = nf;
+  a.channel = o->channel; a.source = o->source; a.dt = o->llr_dtype;
+  a.p = o->param; a.sigma = o->param;
+  if (o->channel == LDPC_CH_BSC_EXACT) {
+    int modified = (int)(c.n * o->param + 0.5);          // bsc(), :44-47
+    if (modified > c.n) modified = c.n;
+    a.flips = modified;
+    const double p = modified / (double)c.n;
+    a.llr_mag = std::log((1.0 - p) / p);                 // +inf when no bit flips, as in the reference
+  } else if (o->channel == LDPC_CH_BSC_IID) {
+    a.llr_mag = std::log((1.0 - o->param) / o->param);
+  }
+  a.seed = o->seed; a.first_frame = first;
+  a.row_ptr = mc->d_row_ptr.as<int32_t>(); a.col_idx = mc->d_col_idx.as<int32_t>();
+  a.x = mc->d_x.as<uint8_t>(); a.llr = mc->d_llr.p; a.synd = mc->d_synd.as<uint8_t>();
+  const size_t per_frame = (size_t)a.nw * 8;
+  int fpw = (int)((size_t)(96 * 1024) / per_frame);
+  if (fpw > 32) fpw = 32;
+  if (fpw < 1) fpw = 1;
+  a.fpw = fpw;
+  const size_t lds = per_frame * fpw;
+  if (lds > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute((const void *)mc_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (nf + fpw - 1) / fpw;
+  hipLaunchKernelGGL(mc_gen_kernel, dim3(grid), dim3(256), lds, st, a);
+  LAUNCHCHK("mc_gen_kernel");
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_mc_generate(ldpc_mc *mc, const ldpc_mc_opts *o, int nframes, uint8_t *x, void *llr,
+                                uint8_t *synd) {
+  int rc = mc_check(mc, o);
+  if (rc) return rc;
+  if (nframes < 0 || nframes > mc->max_frames) {
+    ldpc_set_error("ldpc_mc_generate: nframes exceeds the decoder's max_frames");
+    return LDPC_ERR_ARG;
+  }
+  if (nframes == 0) return LDPC_OK;
+  HIPCHK(hipSetDevice(mc->device));
+  if ((rc = mc_generate_pass(mc, o, o->first_frame, nframes, nullptr))) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)mc->code->n, m = (size_t)mc->code->m;
+  if (x) HIPCHK(hipMemcpy(x, mc->d_x.p, nframes * n, hipMemcpyDeviceToHost));
+  if (llr) HIPCHK(hipMemcpy(llr, mc->d_llr.p, nframes * n * dt_size(o->llr_dtype), hipMemcpyDeviceToHost));
+  if (synd) HIPCHK(hipMemcpy(synd, mc->d_synd.p, nframes * m, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_mc_run(ldpc_mc *mc, const ldpc_mc_opts *o, int64_t nframes, uint64_t *counters) {
+  int rc = mc_check(mc, o);
+  if (rc) return rc;
+  if (nframes < 0 || !counters) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(mc->device));
+  HIPCHK(hipMemsetAsync(mc->d_counters.p, 0, 64, nullptr));
+  const int n = mc->code->n;
+  for (int64_t done = 0; done < nframes; done += mc->max_frames) {
+    const int nf = (int)std::min<int64_t>(mc->max_frames, nframes - done);
+    if ((rc = mc_generate_pass(mc, o, o->first_frame + (uint64_t)done, nf, nullptr))) return rc;
+    rc = ldpc_decode_batch_device(mc->dec, nf, mc->d_llr.p, o->llr_dtype, mc->d_synd.as<uint8_t>(), o->max_iter,
+                                  mc->d_bits.as<uint8_t>(), mc->d_iters.as<int32_t>(), nullptr,
+                                  mc->d_status.as<int32_t>(), nullptr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(nf), dim3(256), 0, nullptr, n, nf, mc->d_x.as<uint8_t>(),
+                       mc->d_bits.as<uint8_t>(), mc->d_status.as<int32_t>(), mc->d_iters.as<int32_t>(),
+                       mc->d_counters.as<unsigned long long>());
+    LAUNCHCHK("mc_classify_kernel");
+  }
+  HIPCHK(hipMemcpy(counters, mc->d_counters.p, 64, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
+
+// the decoded words / status of the last pass of ldpc_mc_run (tests): host pointers, any may be null
+extern "C" int ldpc_mc_last_pass(ldpc_mc *mc, int nframes, uint8_t *x, uint8_t *bits, int32_t *status,
+                                 int32_t *iters) {
+  if (!mc || nframes < 0 || nframes > mc->max_frames) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(mc->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)mc->code->n;
+  if (x) HIPCHK(hipMemcpy(x, mc->d_x.p, nframes * n, hipMemcpyDeviceToHost));
+  if (bits) HIPCHK(hipMemcpy(bits, mc->d_bits.p, nframes * n, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(hipMemcpy(status, mc->d_status.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(hipMemcpy(iters, mc->d_iters.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}

@@ -35,6 +35,20 @@ class _Opts(C.Structure):
                 ("reserved", C.c_int32 * 10)]
 
 
+class _McOpts(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("source", C.c_int32), ("llr_dtype", C.c_int32), ("max_iter", C.c_int32),
+                ("param", C.c_double), ("seed", C.c_uint64), ("first_frame", C.c_uint64),
+                ("reserved", C.c_int32 * 8)]
+
+
+class CH:
+    BSC_EXACT, BSC_IID, AWGN = range(3)
+
+
+class SRC:
+    RANDOM, FIXED, ZERO = range(3)
+
+
 def lib_path():
     return os.environ.get("LDPC_HIP_LIB", os.path.join(_HERE, "libldpc_hip.so"))
 
@@ -77,6 +91,12 @@ def load_library():
     L.ldpc_code_lds_schedule_stats.argtypes = [vp, ip, ip, vp]
     L.ldpc_decoder_profile.argtypes = [vp, ip]
     L.ldpc_decoder_profile_read.argtypes = [vp, vp, vp]
+    L.ldpc_mc_create.argtypes = [vp, vp, ip, C.POINTER(vp)]
+    L.ldpc_mc_free.argtypes = [vp]
+    L.ldpc_mc_free.restype = None
+    L.ldpc_mc_run.argtypes = [vp, C.POINTER(_McOpts), C.c_int64, vp]
+    L.ldpc_mc_generate.argtypes = [vp, C.POINTER(_McOpts), ip, vp, vp, vp]
+    L.ldpc_mc_last_pass.argtypes = [vp, ip, vp, vp, vp, vp]
     L.ldpc_set_seed.argtypes = [C.c_uint64]
     L.ldpc_set_seed.restype = None
     dp, intp = C.POINTER(C.c_double), C.POINTER(C.c_int)
@@ -263,6 +283,62 @@ class Decoder:
     def close(self):
         if self._h:
             load_library().ldpc_decoder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MonteCarlo:
+    """The trial loop of the reference's *_cw_noise_gen harnesses on the device
+    (include/ldpc_hip.h, ldpc_mc_*): source, enc(), channel, dec(), classification."""
+
+    COUNTERS = ("frames", "not_converged", "undetected", "bit_errors", "iterations", "frames_in_error",
+                "bit_errors_converged")
+    _NP = {DT.F64: np.float64, DT.F32: np.float32, DT.I16: np.int16, DT.I32: np.int32}
+
+    def __init__(self, code, decoder, device=0):
+        L = load_library()
+        self.code, self.decoder = code, decoder
+        h = C.c_void_p()
+        check(L.ldpc_mc_create(code._h, decoder._h, device, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def _opts(channel, param, llr_dtype, max_iter, seed, first_frame, source):
+        o = _McOpts()
+        o.channel, o.source, o.llr_dtype, o.max_iter = channel, source, llr_dtype, max_iter
+        o.param, o.seed, o.first_frame = float(param), int(seed), int(first_frame)
+        return o
+
+    def run(self, nframes, channel, param, llr_dtype, max_iter, seed=1, first_frame=0, source=SRC.RANDOM):
+        o = self._opts(channel, param, llr_dtype, max_iter, seed, first_frame, source)
+        c = np.zeros(8, np.uint64)
+        check(load_library().ldpc_mc_run(self._h, C.byref(o), int(nframes), _ptr(c)))
+        return {k: int(c[i]) for i, k in enumerate(self.COUNTERS)}
+
+    def generate(self, nframes, channel, param, llr_dtype, seed=1, first_frame=0, source=SRC.RANDOM):
+        o = self._opts(channel, param, llr_dtype, 0, seed, first_frame, source)
+        x = np.empty((nframes, self.code.n), np.uint8)
+        llr = np.empty((nframes, self.code.n), self._NP[llr_dtype])
+        s = np.empty((nframes, self.code.m), np.uint8)
+        check(load_library().ldpc_mc_generate(self._h, C.byref(o), int(nframes), _ptr(x), _ptr(llr), _ptr(s)))
+        return x, llr, s
+
+    def last_pass(self, nframes):
+        x = np.empty((nframes, self.code.n), np.uint8)
+        bits = np.empty((nframes, self.code.n), np.uint8)
+        status = np.empty(nframes, np.int32)
+        iters = np.empty(nframes, np.int32)
+        check(load_library().ldpc_mc_last_pass(self._h, int(nframes), _ptr(x), _ptr(bits), _ptr(status), _ptr(iters)))
+        return x, bits, status, iters
+
+    def close(self):
+        if self._h:
+            load_library().ldpc_mc_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,0 +1,140 @@
+"""Device Monte-Carlo front-end (ldpc_mc_*) against its numpy
+restatement (oracle/mc_frontend.py) and the decoder oracle.
+
+The random numbers are the library's own counter-based stream (the reference seeds
+rand() from the clock: parity unpinned for the stream); what is checked bit for bit is
+the law of the reference's harness loop: source word, enc(), bsc() with exactly
+round(n p) flips and the corrected LLR magnitude, float_to_fix / float2fix, the
+classification into errors[0] / errors[1], and independence from batching / sharding.
+"""
+import numpy as np
+import pytest
+
+from conftest import code_path
+from oracle import mc_frontend as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(hip, name, alg, max_frames=128, early_exit=True):
+    code = hip.Code.from_alist(code_path(name))
+    dec = hip.Decoder(code, alg, max_frames=max_frames, early_exit=early_exit)
+    return code, dec, hip.MonteCarlo(code, dec)
+
+
+@pytest.mark.parametrize("name,F", [("204.33.484.txt", 70), ("peg_16000_3_0.9.txt", 5), ("1057.244.3.txt", 33)])
+@pytest.mark.parametrize("channel,param", [(ref.BSC_EXACT, 0.031), (ref.BSC_IID, 0.05)])
+@pytest.mark.parametrize("dtype", [ref.I16, ref.F64, ref.I32, ref.F32])
+def test_generation_bsc_is_bit_exact(hip, name, F, channel, param, dtype):
+    code, dec, mc = _setup(hip, name, hip.ALG.MINSUM_Q88)
+    rp, ci, _ = code.csr()
+    x, llr, s = mc.generate(F, channel, param, dtype, seed=77, first_frame=1000)
+    rx, rllr, rs, d = ref.generate(code.n, rp, ci, F, channel, param, dtype, 77, first_frame=1000)
+    assert np.array_equal(x, rx) and np.array_equal(s, rs)
+    assert llr.dtype == rllr.dtype and np.array_equal(llr, rllr)
+    if channel == ref.BSC_EXACT:                      # bsc(): exactly round(n p) flips in every frame
+        flips = ((d < 0) != (rx == 1)).sum(axis=1)
+        assert (flips == int(code.n * param + 0.5)).all()
+    assert 0.35 < x.mean() < 0.65
+
+
+def test_generation_awgn_within_libm_tolerance(hip):
+    """Box-Muller goes through log / sqrt / cos: device and glibc differ in the last ulp.
+    Tolerance: 1e-12 relative on the binary64 LLRs; the Q8.8 words may then differ by one
+    step where an LLR sits on a rounding boundary (none expected in 14 000 values)."""
+    code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88)
+    rp, ci, _ = code.csr()
+    x, llr, s = mc.generate(70, ref.AWGN, 0.8, ref.F64, seed=5)
+    rx, rllr, rs, _ = ref.generate(code.n, rp, ci, 70, ref.AWGN, 0.8, ref.F64, 5)
+    assert np.array_equal(x, rx) and np.array_equal(s, rs)
+    assert np.allclose(llr, rllr, rtol=1e-12, atol=1e-12)
+    sigma_hat = np.std(llr * 0.8 * 0.8 / 2 - (1 - 2.0 * x))
+    assert abs(sigma_hat - 0.8) < 0.02
+    _, q, _ = mc.generate(70, ref.AWGN, 0.8, ref.I16, seed=5)
+    rq = ref.float_to_fix_raw(rllr)
+    assert (np.abs(q.astype(np.int32) - rq.astype(np.int32)) <= 1).all() and (q != rq).mean() < 1e-3
+
+
+def test_frames_do_not_depend_on_batching(hip):
+    code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88)
+    a = mc.generate(40, ref.BSC_EXACT, 0.04, ref.I16, seed=3, first_frame=0)
+    b = mc.generate(9, ref.BSC_EXACT, 0.04, ref.I16, seed=3, first_frame=17)
+    for u, v in zip(a, b):
+        assert np.array_equal(u[17:26], v)
+    fx = mc.generate(6, ref.BSC_EXACT, 0.04, ref.I16, seed=3, source=hip.SRC.FIXED)[0]
+    assert (fx == fx[0]).all() and fx.any()
+    assert not mc.generate(6, ref.BSC_EXACT, 0.04, ref.I16, seed=3, source=hip.SRC.ZERO)[0].any()
+
+
+@pytest.mark.parametrize("alg_name,dtype,p,it", [("MINSUM_Q88", ref.I16, 0.055, 20), ("MINSUM_F64", ref.F64, 0.045, 20)])
+def test_run_counters_match_the_oracle(hip, oracle, alg_name, dtype, p, it):
+    """300 trials in passes of 128: the eight counters equal what the CPU decoder gives on the
+    restated frames (both decoders are bit-exact, so the counts are too)."""
+    name, F = "204.33.484.txt", 300
+    code, dec, mc = _setup(hip, name, getattr(hip.ALG, alg_name))
+    rp, ci, _ = code.csr()
+    got = mc.run(F, ref.BSC_EXACT, p, dtype, it, seed=2024, first_frame=50)
+    x, llr, s, d = ref.generate(code.n, rp, ci, F, ref.BSC_EXACT, p, dtype, 2024, first_frame=50)
+    oc = oracle.load(code_path(name))
+    want = dict(frames=F, not_converged=0, undetected=0, bit_errors=0, iterations=0, frames_in_error=0,
+                bit_errors_converged=0)
+    rcs = []
+    for f in range(F):
+        if alg_name == "MINSUM_Q88":
+            r = oracle.dec_minsum_fixed(oc, llr[f].astype(np.float64) / 256.0, s[f].astype(np.int32), it, None, oc.m + 1)
+        else:
+            r = oracle.dec_minsum(oc, d[f], s[f].astype(np.int32), it)
+        nerr = int((r["bits"].astype(np.uint8) != x[f]).sum())
+        rcs.append(int(r["rc"] != 0))
+        want["not_converged"] += r["rc"] != 0
+        want["undetected"] += r["rc"] == 0 and nerr > 0
+        want["bit_errors"] += nerr
+        want["frames_in_error"] += nerr > 0
+        want["bit_errors_converged"] += nerr if r["rc"] == 0 else 0
+        want["iterations"] += r["iters"]
+    assert got == {k: int(v) for k, v in want.items()}
+    assert 0 < got["not_converged"] < F                      # the operating point exercises both outcomes
+    # the last pass (300 - 256 = 44 frames) is still on the device
+    lx, lbits, lstatus, _ = mc.last_pass(44)
+    assert np.array_equal(lx, x[256:]) and (lstatus != 0).astype(int).tolist() == rcs[256:]
+
+
+def test_run_is_sharding_independent(hip):
+    code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88, max_frames=64)
+    whole = mc.run(500, ref.BSC_EXACT, 0.05, ref.I16, 15, seed=9)
+    a = mc.run(230, ref.BSC_EXACT, 0.05, ref.I16, 15, seed=9, first_frame=0)
+    b = mc.run(270, ref.BSC_EXACT, 0.05, ref.I16, 15, seed=9, first_frame=230)
+    assert whole == {k: a[k] + b[k] for k in whole}
+    assert whole != mc.run(500, ref.BSC_EXACT, 0.05, ref.I16, 15, seed=10)
+
+
+def test_headline_code_runs_on_device(hip, oracle):
+    """PEG-16000 through the fused decoder, 600 frames in passes of 256: well below threshold
+    nearly everything converges to x (plain min-sum on a column-weight-3 code keeps a small
+    floor), far above it nothing does; a 40-frame run is checked against the CPU decoder."""
+    name = "peg_16000_3_0.9.txt"
+    code, dec, mc = _setup(hip, name, hip.ALG.MINSUM_Q88, max_frames=256)
+    lo = mc.run(600, ref.BSC_EXACT, 0.001, ref.I16, 30, seed=1)
+    assert lo["frames"] == 600 and lo["not_converged"] < 30 and lo["undetected"] == 0
+    assert lo["bit_errors_converged"] == 0 and (lo["bit_errors"] > 0) == (lo["not_converged"] > 0)
+    hi = mc.run(600, ref.BSC_IID, 0.03, ref.I16, 5, seed=1)
+    assert hi["not_converged"] == 600 and hi["iterations"] == 3000 and hi["bit_errors"] > 600 * 100
+    F, it, p = 40, 12, 0.0035
+    got = mc.run(F, ref.BSC_EXACT, p, ref.I16, it, seed=8)
+    rp, ci, _ = code.csr()
+    x, llr, s, _ = ref.generate(code.n, rp, ci, F, ref.BSC_EXACT, p, ref.I16, 8)
+    oc = oracle.load(code_path(name))
+    res = [oracle.dec_minsum_fixed(oc, llr[f] / 256.0, s[f].astype(np.int32), it, None, oc.m + 1) for f in range(F)]
+    assert got["not_converged"] == sum(r["rc"] != 0 for r in res)
+    assert got["iterations"] == sum(r["iters"] for r in res)
+    assert got["bit_errors"] == sum(int((r["bits"].astype(np.uint8) != x[f]).sum()) for f, r in enumerate(res))
+
+
+def test_bad_arguments(hip):
+    code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88)
+    with pytest.raises(hip.LdpcError):
+        mc.run(10, ref.BSC_EXACT, 1.5, ref.I16, 5)
+    with pytest.raises(hip.LdpcError):
+        mc.run(10, 7, 0.1, ref.I16, 5)
+    with pytest.raises(hip.LdpcError):
+        mc.generate(1000, ref.BSC_EXACT, 0.1, ref.I16)       # more than one pass
