@@ -2,10 +2,11 @@
 //
 // Same names, argument order and meaning as the C harness functions of the
 // reference (see include/ldpc_hip.h for the file:line of each).  They are thin
-// Monte-Carlo / single-frame drivers on the host: source bits, syndrome, BSC
-// or confusion-matrix channel and the error classification happen here, every
-// dec() call goes to the GPU through ldpc_decode_batch().  There is no CPU
-// decoder behind them: without a HIP device they return LDPC_ERR_HIP.
+// drivers: the binary Monte-Carlo harnesses hand the whole trial loop to the
+// device front-end (mc_frontend.hip); the single-frame harnesses and GFq_LDPC
+// (confusion-matrix channel) prepare their frames here and every dec() call
+// goes to the GPU through ldpc_decode_batch().  There is no CPU decoder behind
+// them: without a HIP device they return LDPC_ERR_HIP.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -63,6 +64,7 @@ struct Cached {
   int alg;
   ldpc_code *code;
   ldpc_decoder *dec;
+  ldpc_mc *mc;        // device Monte-Carlo context (binary codes), made on first use
 };
 std::vector<Cached> g_cache;
 
@@ -74,13 +76,25 @@ int mc_batch() {
   return 1024;
 }
 
-int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec) {
+int cache_device() {
+  if (const char *e = getenv("LDPC_HIP_DEVICE")) return atoi(e);
+  return 0;
+}
+
+int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec, ldpc_mc **mc = nullptr) {
   if (!file) return LDPC_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto &c : g_cache)
     if (c.alg == alg && c.file == file) {
       *code = c.code;
       *dec = c.dec;
+      if (mc) {
+        if (!c.mc) {
+          int rc = ldpc_mc_create(c.code, c.dec, cache_device(), &c.mc);
+          if (rc) return rc;
+        }
+        *mc = c.mc;
+      }
       return LDPC_OK;
     }
   ldpc_code *c = nullptr;
@@ -89,8 +103,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec)
   ldpc_opts o;
   memset(&o, 0, sizeof o);
   o.alg = alg;
-  o.device = 0;
-  if (const char *e = getenv("LDPC_HIP_DEVICE")) o.device = atoi(e);
+  o.device = cache_device();
   o.max_frames = mc_batch();
   o.early_exit = 1;
   ldpc_decoder *d = nullptr;
@@ -99,7 +112,17 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec)
     ldpc_code_free(c);
     return rc;
   }
-  g_cache.push_back({file, alg, c, d});
+  ldpc_mc *m = nullptr;
+  if (mc) {
+    rc = ldpc_mc_create(c, d, o.device, &m);
+    if (rc) {
+      ldpc_decoder_free(d);
+      ldpc_code_free(c);
+      return rc;
+    }
+    *mc = m;
+  }
+  g_cache.push_back({file, alg, c, d, m});
   *code = c;
   *dec = d;
   return LDPC_OK;
@@ -128,41 +151,11 @@ struct HostGraph {
   }
 };
 
-// bsc(), test_code_min_sum_B.c:41-67: exactly round(n p) distinct flips, the
-// LLR magnitude uses the corrected p.  Returns that magnitude.
-double bsc(int n, double p, const uint8_t *x, uint8_t *y, Rng &r, std::vector<uint8_t> &err) {
-  int modified = (int)(n * p + 0.5);
-  if (modified > n) modified = n;
-  if (modified < 0) modified = 0;
-  p = modified / (double)n;
-  err.assign(n, 0);
-  int num = 0;
-  while (num < modified) {
-    uint32_t i = r.below((uint32_t)n);
-    if (err[i]) continue;
-    err[i] = 1;
-    num++;
-  }
-  for (int i = 0; i < n; i++) y[i] = x[i] ^ err[i];
-  return std::log((1.0 - p) / p);
-}
-
 enum Prep { PREP_NONE, PREP_Q88, PREP_Q14 };
 
-// float_to_fix(), test_code_min_sum_B_fixed.c:43-53 (INT_LEVELS 128, FRAC_LEVELS 256)
-double float_to_fix(double v) {
-  double r = std::round(v * 256.0) / 256.0;
-  if (r > 127) return 127;
-  if (r < -128) return -128;
-  return r;
-}
-// float2fix(), test_code_B.c:36-43
-int float2fix14(double x) {
-  if (x >= 0) return (int)(x * 16384.0 + 0.5);
-  return -(int)((-x) * 16384.0 + 0.5);
-}
-
-// The Monte-Carlo loop shared by the *_cw_noise_gen harnesses and test_code_B.
+// The Monte-Carlo loop shared by the *_cw_noise_gen harnesses and test_code_B: the whole
+// trial loop (source word, enc(), bsc(), dec(), classification) runs on the device
+// (mc_frontend.hip); only the counters come back.
 //   fresh_x: draw x per trial (mex harnesses) or once (test_code_no_mex_B.c:339-343)
 int monte_carlo_bsc(const char *file, int alg, int iteration, int trials, double p_bsc, bool fresh_x,
                     Prep prep, double *errors) {
@@ -171,50 +164,23 @@ int monte_carlo_bsc(const char *file, int alg, int iteration, int trials, double
   if (trials < 0 || iteration < 0) return LDPC_ERR_ARG;
   ldpc_code *code;
   ldpc_decoder *dec;
-  int rc = get_decoder(file, alg, &code, &dec);
+  ldpc_mc *mc = nullptr;
+  int rc = get_decoder(file, alg, &code, &dec, &mc);
   if (rc) return rc;
-  HostGraph g(code);
-  if (g.q != 2) return LDPC_ERR_UNSUPPORTED;
   Rng r = take_rng();
-  const int n = g.n, m = g.m;
-  const int B = ldpc_decoder_max_frames(dec);
-  std::vector<uint8_t> x((size_t)B * n), y(n), s((size_t)B * m), bits((size_t)B * n), err;
-  std::vector<double> q0;
-  std::vector<int32_t> q0i, status(B);
-  if (prep == PREP_Q14) q0i.resize((size_t)B * n);
-  else q0.resize((size_t)B * n);
-  if (!fresh_x) {
-    for (int j = 0; j < n; j++) x[j] = (uint8_t)r.bit();
-    g.enc_bin(x.data(), s.data());
-    for (int f = 1; f < B; f++) {
-      memcpy(&x[(size_t)f * n], x.data(), n);
-      memcpy(&s[(size_t)f * m], s.data(), m);
-    }
-  }
-  for (int t0 = 0; t0 < trials; t0 += B) {
-    const int nf = trials - t0 < B ? trials - t0 : B;
-    for (int f = 0; f < nf; f++) {
-      uint8_t *xf = &x[(size_t)f * n];
-      if (fresh_x) {
-        for (int j = 0; j < n; j++) xf[j] = (uint8_t)r.bit();
-        g.enc_bin(xf, &s[(size_t)f * m]);
-      }
-      const double L = bsc(n, p_bsc, xf, y.data(), r, err);
-      for (int j = 0; j < n; j++) {
-        const double d = (1 - 2 * (int)y[j]) * L;
-        if (prep == PREP_Q14) q0i[(size_t)f * n + j] = float2fix14(d);
-        else q0[(size_t)f * n + j] = prep == PREP_Q88 ? float_to_fix(d) : d;
-      }
-    }
-    rc = ldpc_decode_batch(dec, nf, prep == PREP_Q14 ? (const void *)q0i.data() : (const void *)q0.data(),
-                           prep == PREP_Q14 ? LDPC_DT_I32 : LDPC_DT_F64, s.data(), iteration, bits.data(),
-                           nullptr, nullptr, status.data(), nullptr);
-    if (rc) return rc;
-    for (int f = 0; f < nf; f++) {
-      if (status[f]) errors[0]++;
-      else if (memcmp(&bits[(size_t)f * n], &x[(size_t)f * n], n) != 0) errors[1]++;
-    }
-  }
+  ldpc_mc_opts o;
+  memset(&o, 0, sizeof o);
+  o.channel = LDPC_CH_BSC_EXACT;
+  o.source = fresh_x ? LDPC_SRC_RANDOM : LDPC_SRC_FIXED;
+  o.llr_dtype = prep == PREP_Q88 ? LDPC_DT_I16 : prep == PREP_Q14 ? LDPC_DT_I32 : LDPC_DT_F64;
+  o.max_iter = iteration;
+  o.param = p_bsc;
+  o.seed = r.next();
+  uint64_t counters[8];
+  rc = ldpc_mc_run(mc, &o, trials, counters);
+  if (rc) return rc;
+  errors[0] = (double)counters[1];
+  errors[1] = (double)counters[2];
   return LDPC_OK;
 }
 
