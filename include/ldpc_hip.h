@@ -205,7 +205,10 @@ typedef enum ldpc_channel {
   LDPC_CH_BSC_EXACT = 0, /* the reference's bsc(): exactly round(n p) distinct flips, LLR
                             magnitude log((1-p')/p') with p' = flips / n                   */
   LDPC_CH_BSC_IID   = 1, /* independent flips with probability p                           */
-  LDPC_CH_AWGN      = 2  /* BPSK 1-2x plus N(0, sigma^2); LLR = 2 y / sigma^2              */
+  LDPC_CH_AWGN      = 2, /* BPSK 1-2x plus N(0, sigma^2); LLR = 2 y / sigma^2              */
+  LDPC_CH_QLC       = 3  /* channel() of test_code_B_MSDP.c:411-440: 4 bits per flash cell,
+                            Gray mapped, read drawn from a confusion matrix, bit LLRs from
+                            assign_llr_one_sym() (:339-395); tables: ldpc_mc_set_qlc_channel */
 } ldpc_channel;
 typedef enum ldpc_source {
   LDPC_SRC_RANDOM = 0,   /* a fresh random word per frame (the mex harnesses)              */
@@ -230,6 +233,10 @@ typedef struct ldpc_mc ldpc_mc;
  * decoder's device).  The code and the decoder must outlive the context. */
 int  ldpc_mc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_mc **out);
 void ldpc_mc_free(ldpc_mc *mc);
+/* Tables of LDPC_CH_QLC from p_rec_given_sent[rows][16] (P(i received | j sent), columns
+ * already normalised as test_code_B_MSDP.c:455-465 does; rows = 16 for num_reads 1, 46
+ * for 3): make_p_sent_given_rec_T() (:297-323) and the per-page bit LLRs (:339-395). */
+int  ldpc_mc_set_qlc_channel(ldpc_mc *mc, const double *p_rec_given_sent, int num_reads);
 /* Runs nframes trials; counters[8] = {frames, not converged (errors[0]),
  * converged to a word != x (errors[1]), bit errors over all frames, iterations
  * executed, frames with any bit error, bit errors of converged frames, 0}. */
@@ -273,6 +280,14 @@ int test_code_B_float_cw_noise_gen(const char *code_filename, int iteration, int
  * x is drawn once, as that driver does at :339-343).  The mex variant
  * (test_code_B.c:316-360) is the same call with H_file = "peg_16000_3_0.9.txt". */
 int test_code_B(int iteration, int trials, double p_bsc, const char *H_file, double *errors);
+/* test_code_B_MSDP(), test_code_B_MSDP.c:442-543, decode_mode 0 (random data through
+ * the QLC confusion-matrix channel, float sum-product dec()); the whole loop runs on the
+ * device.  The reference hard-codes "peg_16000_3_0.9.txt" (:467); here the code file is
+ * an argument.  p_rec_given_sent is [16 or 46][16] row-major and is column-normalised in
+ * place like the reference (:455-465).  decode_mode 1 replays snowbird_sym.bin, which
+ * the reference does not ship: LDPC_ERR_UNSUPPORTED. */
+int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, int num_reads,
+                     int decode_mode, double *p_rec_given_sent, double *errors);
 /* GFq_LDPC(), GFq_LDPC.c:540-655, decode_mode 0 (synthetic symbols through the
  * confusion-matrix channel).  The reference hard-codes "547_NB.txt"; here the
  * code file is an argument.  p_rec_given_sent is [q*num_reads][q] row-major

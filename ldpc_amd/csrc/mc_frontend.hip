@@ -25,11 +25,16 @@
 // found by rejection on uniform draws, LLR magnitude log((1-p')/p') with p' = flips/n.
 // BSC_IID flips every bit independently with probability p (LLR magnitude from p).
 // AWGN: BPSK, y = (1 - 2x) + sigma N(0,1), LLR = 2 y / sigma^2 (Box-Muller).
+// QLC: the multi-read flash front-end of test_code_B_MSDP.c: four bits per cell, Gray
+// mapped to one of 16 levels (:422), the read drawn from the caller's confusion matrix by
+// the reference's percent-granular inverse CDF (:424-436), bit LLRs looked up in the
+// table that make_p_sent_given_rec_T() / assign_llr_one_sym() (:297-395) define.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "engine.h"
 
@@ -60,6 +65,9 @@ struct McArgs {
   uint8_t *x;                 // [nframes][n]
   void *llr;                  // [nframes][n] of dt
   uint8_t *synd;              // [nframes][m]
+  // QLC channel: column-normalised confusion matrix [rows][16] and bit-LLR table [rows][4]
+  const double *conf, *llr_tab;
+  int rows;
 };
 
 // float_to_fix() of test_code_min_sum_B_fixed.c:43-53, raw (value * 256)
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) void mc_gen_kernel(McArgs a) {
       const int xi = (xb[i >> 5] >> (i & 31)) & 1;
       a.x[row + i] = (uint8_t)xi;
       double d;
+      if (a.channel == 3) continue;            // QLC: LLRs are written per cell below
       if (a.channel == 2) {
         const double u1 = (double)((draw(key, 2 * (uint64_t)i) >> 11) + 1) * (1.0 / 9007199254740992.0);
         const double u2 = (double)(draw(key, 2 * (uint64_t)i + 1) >> 11) * (1.0 / 9007199254740992.0);
@@ -157,6 +166,36 @@ __global__ __launch_bounds__(256) void mc_gen_kernel(McArgs a) {
         d = (double)(1 - 2 * yi) * a.llr_mag;   // q0[i] = (1 - 2 y[i]) log((1-p)/p), :63-66
       }
       store_llr(a.llr, a.dt, row + i, d);
+    }
+  }
+
+  if (a.channel == 3) {
+    // channel() of test_code_B_MSDP.c:411-440, one thread per cell
+    const int grey_code_inv[16] = {6, 5, 7, 14, 9, 12, 8, 13, 3, 4, 2, 15, 10, 11, 1, 0};   // :23
+    const int cells = a.n >> 2;
+    for (int t = tid; t < nf * cells; t += B) {
+      const int f = t / cells, c = t % cells;
+      const uint32_t *xb = bm + (f * 2 + 0) * nw;
+      const int nib = (xb[c >> 3] >> ((c & 7) * 4)) & 15;      // x[4c+3..4c] as (tp up mp lp)
+      const int symbol = grey_code_inv[nib];
+      const uint64_t key = stream_key(a.seed, a.first_frame + (uint64_t)(f0 + f), 1);
+      const int rand_select = (int)(((draw(key, (uint64_t)c) >> 32) * 101ull) >> 32);   // rand() % 101
+      double temp = 0;
+      int rec = 0;
+      if (!rand_select)
+        while (rec < a.rows && !a.conf[(rec++) * 16 + symbol]) {}
+      {
+        // separately rounded product and sum, as the reference's x86-64 build computes them:
+        // a fused multiply-add moves the walk by one bin when the sum lands on rand_select
+#pragma clang fp contract(off)
+        while (temp < rand_select && rec != a.rows) {
+          const double step = 100 * a.conf[(rec++) * 16 + symbol];
+          temp = temp + step;
+        }
+      }
+      rec = rec > 0 ? rec - 1 : 0;
+      const size_t at = (size_t)(f0 + f) * a.n + 4 * (size_t)c;
+      for (int b = 0; b < 4; b++) store_llr(a.llr, a.dt, at + b, a.llr_tab[rec * 4 + b]);
     }
   }
 
@@ -212,6 +251,8 @@ struct ldpc_mc {
   ldpc_decoder *dec = nullptr;
   int device = 0, max_frames = 0;
   DevBuf d_row_ptr, d_col_idx, d_x, d_llr, d_synd, d_bits, d_iters, d_status, d_counters;
+  DevBuf d_conf, d_llr_tab;   // QLC channel tables (ldpc_mc_set_qlc_channel)
+  int qlc_rows = 0;
 };
 
 extern "C" int ldpc_mc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_mc **out) {
@@ -252,12 +293,21 @@ extern "C" void ldpc_mc_free(ldpc_mc *mc) {
 
 static int mc_check(const ldpc_mc *mc, const ldpc_mc_opts *o) {
   if (!mc || !o) return LDPC_ERR_ARG;
-  if (o->channel < 0 || o->channel > 2 || o->source < 0 || o->source > 2 || o->llr_dtype < 0 || o->llr_dtype > 3 ||
+  if (o->channel < 0 || o->channel > 3 || o->source < 0 || o->source > 2 || o->llr_dtype < 0 || o->llr_dtype > 3 ||
       o->max_iter < 0) {
     ldpc_set_error("ldpc_mc: bad channel / source / dtype / max_iter");
     return LDPC_ERR_ARG;
   }
-  if (o->channel == LDPC_CH_AWGN ? !(o->param > 0) : !(o->param > 0 && o->param < 1)) {
+  if (o->channel == LDPC_CH_QLC) {
+    if (!mc->qlc_rows) {
+      ldpc_set_error("ldpc_mc: LDPC_CH_QLC needs ldpc_mc_set_qlc_channel() first");
+      return LDPC_ERR_ARG;
+    }
+    if (mc->code->n % 4) {
+      ldpc_set_error("ldpc_mc: the QLC front-end needs n to be a multiple of 4 (test_code_B_MSDP.c:397)");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+  } else if (o->channel == LDPC_CH_AWGN ? !(o->param > 0) : !(o->param > 0 && o->param < 1)) {
     ldpc_set_error("ldpc_mc: channel parameter out of range (BSC: 0 < p < 1, AWGN: sigma > 0)");
     return LDPC_ERR_ARG;
   }
@@ -282,6 +332,7 @@ static int mc_generate_pass(ldpc_mc *mc, const ldpc_mc_opts *o, uint64_t first, 
   } else if (o->channel == LDPC_CH_BSC_IID) {
     a.llr_mag = std::log((1.0 - o->param) / o->param);
   }
+  a.conf = mc->d_conf.as<double>(); a.llr_tab = mc->d_llr_tab.as<double>(); a.rows = mc->qlc_rows;
   a.seed = o->seed; a.first_frame = first;
   a.row_ptr = mc->d_row_ptr.as<int32_t>(); a.col_idx = mc->d_col_idx.as<int32_t>();
   a.x = mc->d_x.as<uint8_t>(); a.llr = mc->d_llr.p; a.synd = mc->d_synd.as<uint8_t>();
@@ -296,6 +347,40 @@ static int mc_generate_pass(ldpc_mc *mc, const ldpc_mc_opts *o, uint64_t first, 
   const int grid = (nf + fpw - 1) / fpw;
   hipLaunchKernelGGL(mc_gen_kernel, dim3(grid), dim3(256), lds, st, a);
   LAUNCHCHK("mc_gen_kernel");
+  return LDPC_OK;
+}
+
+// Tables of the QLC front-end from a column-normalised confusion matrix
+// p_rec_given_sent[rows][16] (rows = 16 for one read, 46 for three: test_code_B_MSDP.c:302-306).
+extern "C" int ldpc_mc_set_qlc_channel(ldpc_mc *mc, const double *p_rec_given_sent, int num_reads) {
+  if (!mc || !p_rec_given_sent || (num_reads != 1 && num_reads != 3)) {
+    ldpc_set_error("ldpc_mc_set_qlc_channel: num_reads must be 1 or 3");
+    return LDPC_ERR_ARG;
+  }
+  constexpr int Q = 16;
+  const int rows = num_reads == 1 ? Q : Q * num_reads - 2;
+  // bits that read 1 on the lower / middle / upper / top page, :24-27
+  static const int sym_low_1[8] = {0, 4, 5, 11, 12, 13, 14, 15}, sym_mid_1[8] = {0, 1, 2, 7, 8, 13, 14, 15},
+                   sym_up_1[8] = {0, 1, 8, 9, 10, 11, 12, 13}, sym_top_1[8] = {0, 1, 2, 3, 4, 10, 11, 15};
+  const int *sets[4] = {sym_low_1, sym_mid_1, sym_up_1, sym_top_1};
+  std::vector<double> T((size_t)rows * Q), tab((size_t)rows * 4);
+  const double P_x = 1 / (1.0 * Q);
+  for (int i = 0; i < rows; i++) {                       // make_p_sent_given_rec_T(), :297-323
+    double P_y = 0;
+    for (int j = 0; j < Q; j++) P_y += p_rec_given_sent[i * Q + j] * P_x;
+    for (int j = 0; j < Q; j++) T[(size_t)i * Q + j] = P_y ? P_x * p_rec_given_sent[i * Q + j] / P_y : 0.0;
+    for (int b = 0; b < 4; b++) {                        // assign_llr_one_sym(), :339-395
+      double Pr_1 = 0;
+      for (int j = 0; j < 8; j++) Pr_1 += T[(size_t)i * Q + sets[b][j]];
+      tab[(size_t)i * 4 + b] = Pr_1 == 1 ? -100.0 : Pr_1 == 0 ? 100.0 : std::log((1.0 - Pr_1) / Pr_1);
+    }
+  }
+  HIPCHK(hipSetDevice(mc->device));
+  int rc;
+  if ((rc = mc->d_conf.ensure((size_t)rows * Q * 8)) || (rc = mc->d_llr_tab.ensure((size_t)rows * 4 * 8))) return rc;
+  HIPCHK(hipMemcpy(mc->d_conf.p, p_rec_given_sent, (size_t)rows * Q * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(mc->d_llr_tab.p, tab.data(), (size_t)rows * 4 * 8, hipMemcpyHostToDevice));
+  mc->qlc_rows = rows;
   return LDPC_OK;
 }
 

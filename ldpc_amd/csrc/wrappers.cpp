@@ -265,6 +265,43 @@ extern "C" int test_code_B(int iteration, int trials, double p_bsc, const char *
   return monte_carlo_bsc(H_file, LDPC_ALG_SPA_TABLE_Q14, iteration, trials, p_bsc, false, PREP_Q14, errors);
 }
 
+// test_code_B_MSDP(), test_code_B_MSDP.c:442-543
+extern "C" int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, int num_reads,
+                                int decode_mode, double *p_rec_given_sent, double *errors) {
+  if (!errors) return LDPC_ERR_ARG;
+  errors[0] = errors[1] = 0;
+  if (!p_rec_given_sent || (num_reads != 1 && num_reads != 3) || num_trials < 0 || iteration < 0) return LDPC_ERR_ARG;
+  if (decode_mode != 0) {
+    ldpc_set_error("test_code_B_MSDP: decode_mode 1 (snowbird_sym.bin page file) is not supported");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  const int Q = 16, R = num_reads == 1 ? Q : Q * num_reads - 2;
+  for (int i = 0; i < Q; i++) {                      // column normalisation in place, :455-465
+    double norm = 0;
+    for (int j = 0; j < R; j++) norm += p_rec_given_sent[j * Q + i];
+    for (int j = 0; j < R; j++) p_rec_given_sent[j * Q + i] /= norm;
+  }
+  ldpc_code *code;
+  ldpc_decoder *dec;
+  ldpc_mc *mc = nullptr;
+  int rc = get_decoder(code_filename, LDPC_ALG_SPA_F64, &code, &dec, &mc);
+  if (rc) return rc;
+  if ((rc = ldpc_mc_set_qlc_channel(mc, p_rec_given_sent, num_reads))) return rc;
+  Rng r = take_rng();
+  ldpc_mc_opts o;
+  memset(&o, 0, sizeof o);
+  o.channel = LDPC_CH_QLC;
+  o.source = LDPC_SRC_RANDOM;
+  o.llr_dtype = LDPC_DT_F64;
+  o.max_iter = iteration;
+  o.seed = r.next();
+  uint64_t counters[8];
+  if ((rc = ldpc_mc_run(mc, &o, num_trials, counters))) return rc;
+  errors[0] = (double)counters[1];
+  errors[1] = (double)counters[2];
+  return LDPC_OK;
+}
+
 // GFq_LDPC(), GFq_LDPC.c:540-655
 extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
                         int num_reads, int decode_mode, double *p_rec_given_sent, double *errors) {

@@ -42,7 +42,7 @@ class _McOpts(C.Structure):
 
 
 class CH:
-    BSC_EXACT, BSC_IID, AWGN = range(3)
+    BSC_EXACT, BSC_IID, AWGN, QLC = range(4)
 
 
 class SRC:
@@ -97,6 +97,7 @@ def load_library():
     L.ldpc_mc_run.argtypes = [vp, C.POINTER(_McOpts), C.c_int64, vp]
     L.ldpc_mc_generate.argtypes = [vp, C.POINTER(_McOpts), ip, vp, vp, vp]
     L.ldpc_mc_last_pass.argtypes = [vp, ip, vp, vp, vp, vp]
+    L.ldpc_mc_set_qlc_channel.argtypes = [vp, vp, ip]
     L.ldpc_set_seed.argtypes = [C.c_uint64]
     L.ldpc_set_seed.restype = None
     dp, intp = C.POINTER(C.c_double), C.POINTER(C.c_int)
@@ -108,6 +109,7 @@ def load_library():
     L.test_code_B_float_cw_noise_gen.argtypes = [cp, ip, ip, C.c_double, dp]
     L.test_code_B.argtypes = [ip, ip, C.c_double, cp, dp]
     L.GFq_LDPC.argtypes = [cp, ip, ip, ip, ip, ip, dp, dp]
+    L.test_code_B_MSDP.argtypes = [cp, ip, ip, ip, ip, dp, dp]
     _lib = L
     return L
 
@@ -327,6 +329,11 @@ class MonteCarlo:
         s = np.empty((nframes, self.code.m), np.uint8)
         check(load_library().ldpc_mc_generate(self._h, C.byref(o), int(nframes), _ptr(x), _ptr(llr), _ptr(s)))
         return x, llr, s
+
+    def set_qlc_channel(self, p_rec_given_sent, num_reads):
+        """Confusion matrix [16 or 46][16], columns normalised (test_code_B_MSDP.c:455-465)."""
+        p = np.ascontiguousarray(p_rec_given_sent, np.float64)
+        check(load_library().ldpc_mc_set_qlc_channel(self._h, _ptr(p), int(num_reads)))
 
     def last_pass(self, nframes):
         x = np.empty((nframes, self.code.n), np.uint8)

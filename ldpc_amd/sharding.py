@@ -37,3 +37,18 @@ def reduce_max(value, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def run_sharded(mc, total_frames, channel, param, llr_dtype, max_iter, seed=1, device=None, **kw):
+    """One sweep point over all ranks: rank r runs the device Monte-Carlo loop
+    (ldpc_amd.MonteCarlo.run) on its own range of global frame indices -- the frames are
+    keyed by that index, so the union is the same run whatever the world size -- and the
+    counters are summed by the path's only collective.  Returns the summed dict."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = frame_range(total_frames, rank, world)
+    part = mc.run(hi - lo, channel, param, llr_dtype, max_iter, seed=seed, first_frame=lo, **kw)
+    keys = list(part)
+    total = reduce_counters([part[k] for k in keys], device=device)
+    return {k: int(v) for k, v in zip(keys, total)}

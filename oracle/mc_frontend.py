@@ -9,6 +9,8 @@ product.  It restates, frame by frame, what ldpc_amd/csrc/mc_frontend.hip genera
                 q0[i] = (1 - 2 y[i]) log((1 - p') / p') test_code_min_sum_B.c:41-67
   float_to_fix  round half away, clip to [-128, 127]    test_code_min_sum_B_fixed.c:43-53
   float2fix     Q8.14, round half away                  test_code_B.c:36-43
+  QLC channel   Gray map, percent-granular inverse CDF  test_code_B_MSDP.c:411-440
+                make_p_sent_given_rec_T, bit LLRs       test_code_B_MSDP.c:297-395
 
 The reference draws from libc rand() seeded with time(NULL) (:289), so there is no
 reference stream to match: PARITY UNPINNED for the random numbers themselves.  What is
@@ -20,7 +22,7 @@ key = mix64(seed ^ mix64(4 frame + s + GOLDEN)), mix64 = the splitmix64 finalise
 import numpy as np
 
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
-BSC_EXACT, BSC_IID, AWGN = range(3)
+BSC_EXACT, BSC_IID, AWGN, QLC = range(4)
 SRC_RANDOM, SRC_FIXED, SRC_ZERO = range(3)
 F64, F32, I16, I32 = range(4)
 
@@ -84,7 +86,54 @@ def bsc_exact_pattern(n, p, seed, frame):
     return err, mag
 
 
-def generate(n, row_ptr, col_idx, nframes, channel, param, dtype, seed, first_frame=0, source=SRC_RANDOM):
+GREY_CODE_INV = [6, 5, 7, 14, 9, 12, 8, 13, 3, 4, 2, 15, 10, 11, 1, 0]            # test_code_B_MSDP.c:23
+SYM_SETS = [[0, 4, 5, 11, 12, 13, 14, 15], [0, 1, 2, 7, 8, 13, 14, 15],         # low, mid (:27, :26)
+            [0, 1, 8, 9, 10, 11, 12, 13], [0, 1, 2, 3, 4, 10, 11, 15]]           # up, top (:25, :24)
+
+
+def qlc_llr_table(conf):
+    """make_p_sent_given_rec_T() (:297-323) then assign_llr_one_sym() (:339-395): [rows][4],
+    sums in the reference's order."""
+    rows, Q = conf.shape
+    P_x = 1 / (1.0 * Q)
+    tab = np.zeros((rows, 4))
+    for i in range(rows):
+        P_y = 0.0
+        for j in range(Q):
+            P_y += conf[i, j] * P_x
+        T = [P_x * conf[i, j] / P_y if P_y else 0.0 for j in range(Q)]
+        for b in range(4):
+            pr1 = 0.0
+            for j in SYM_SETS[b]:
+                pr1 += T[j]
+            with np.errstate(invalid="ignore"):       # a sum one ulp above 1 gives log(<0) = NaN in the reference too
+                tab[i, b] = -100.0 if pr1 == 1 else 100.0 if pr1 == 0 else np.log((1.0 - pr1) / pr1)
+    return tab
+
+
+def qlc_channel(x, conf, tab, key):
+    """channel(), :411-440, with rand() % 101 replaced by the frame's stream."""
+    rows = conf.shape[0]
+    cells = len(x) // 4
+    d = np.zeros(len(x))
+    sel = ((draw(key, np.arange(cells)) >> np.uint64(32)) * np.uint64(101)) >> np.uint64(32)
+    for c in range(cells):
+        symbol = GREY_CODE_INV[(int(x[4 * c + 3]) << 3) + (int(x[4 * c + 2]) << 2) + (int(x[4 * c + 1]) << 1) + int(x[4 * c])]
+        temp, rec, rs = 0.0, 0, int(sel[c])
+        if not rs:
+            while rec < rows:
+                rec += 1
+                if conf[rec - 1, symbol]:
+                    break
+        while temp < rs and rec != rows:
+            temp += 100 * conf[rec, symbol]
+            rec += 1
+        rec = rec - 1 if rec > 0 else 0
+        d[4 * c:4 * c + 4] = tab[rec]
+    return d
+
+
+def generate(n, row_ptr, col_idx, nframes, channel, param, dtype, seed, first_frame=0, source=SRC_RANDOM, conf=None):
     """-> x [F][n] u8, llr [F][n] of dtype, synd [F][m] u8, llr as float64 before quantisation."""
     m = len(row_ptr) - 1
     x = np.zeros((nframes, n), np.uint8)
@@ -97,6 +146,8 @@ def generate(n, row_ptr, col_idx, nframes, channel, param, dtype, seed, first_fr
         if channel == BSC_EXACT:
             err, mag = bsc_exact_pattern(n, param, seed, frame)
             d[f] = (1 - 2 * (x[f] ^ err).astype(np.float64)) * mag
+        elif channel == QLC:
+            d[f] = qlc_channel(x[f], conf, qlc_llr_table(conf), key)
         elif channel == BSC_IID:
             thr = np.uint64(0xFFFFFFFFFFFFFFFF) if param >= 1 else np.uint64(int(param * 18446744073709551616.0))
             err = (draw(key, np.arange(n)) < thr).astype(np.uint8)

@@ -138,3 +138,59 @@ def test_bad_arguments(hip):
         mc.run(10, 7, 0.1, ref.I16, 5)
     with pytest.raises(hip.LdpcError):
         mc.generate(1000, ref.BSC_EXACT, 0.1, ref.I16)       # more than one pass
+
+
+def _confusion(num_reads, noise, seed=0, floor=0.0):
+    """A synthetic confusion matrix p_rec_given_sent[rows][16] in the shape test_mex_B_MSDP.m
+    passes: mass on the sent level, `noise` leaking to the neighbouring read bins; some
+    exact zeros; columns normalised like test_code_B_MSDP.c:455-465."""
+    rows = 16 if num_reads == 1 else 46
+    rng = np.random.default_rng(seed)
+    p = np.zeros((rows, 16))
+    for j in range(16):
+        centre = j if num_reads == 1 else 3 * j
+        for dlt, w in ((0, 1.0), (-1, noise), (1, noise), (-2, noise / 4), (2, noise / 4)):
+            i = centre + dlt
+            if 0 <= i < rows:
+                p[i, j] += w * (0.5 + rng.random())
+    p += floor
+    return p / p.sum(axis=0, keepdims=True)
+
+
+@pytest.mark.parametrize("num_reads", [1, 3])
+def test_qlc_front_end_is_bit_exact(hip, num_reads):
+    """LDPC_CH_QLC against the restated channel() / assign_llr_one_sym() of test_code_B_MSDP.c."""
+    code, dec, mc = _setup(hip, "peg_16000_3_0.9.txt", hip.ALG.SPA_F64, max_frames=64)
+    conf = _confusion(num_reads, 0.06)
+    mc.set_qlc_channel(conf, num_reads)
+    rp, ci, _ = code.csr()
+    x, llr, s = mc.generate(3, ref.QLC, 0.0, ref.F64, seed=21, first_frame=4)
+    rx, rllr, rs, _ = ref.generate(code.n, rp, ci, 3, ref.QLC, 0.0, ref.F64, 21, first_frame=4, conf=conf)
+    assert np.array_equal(x, rx) and np.array_equal(s, rs)
+    bad = np.where(llr != rllr)
+    assert len(bad[0]) == 0, (len(bad[0]), bad[0][::4].tolist(), (bad[1][::4] // 4).tolist(), llr[bad][:8], rllr[bad][:8])
+    tab = ref.qlc_llr_table(conf)
+    assert np.isin(llr.reshape(-1, 4), tab).all() and len(np.unique(llr)) > 8
+
+
+def test_msdp_entry_point(hip):
+    """test_code_B_MSDP() on the rate-1/2 (204,102) code: a mild dense matrix decodes (the CPU
+    restatement of the same channel decodes 60 of 60 there), a very noisy one does not;
+    decode_mode 1 and a bad read count are refused.
+    Why dense and rate 1/2: a read that pins a bit gets LLR +-100 (:348-352) and tanh(50) == 1.0
+    sends the reference's float sum-product to inf - inf, and its sampler maps rand() % 101 == 0
+    to the first bin with non-zero probability (:428-430), i.e. 1 % of the cells of a dense
+    matrix read as bin 0 -- both are the reference's behaviour, restated, not worked round."""
+    import ctypes as C
+    L = hip.load_library()
+    path = code_path("204.33.484.txt").encode()
+    err = np.zeros(2)
+    dp = err.ctypes.data_as(C.POINTER(C.c_double))
+    conf = np.ascontiguousarray(_confusion(3, 0.01, floor=1e-4) * 7.0)   # unnormalised on purpose
+    assert L.test_code_B_MSDP(path, 30, 400, 3, 0, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == 0, L.ldpc_last_error()
+    assert err[0] <= 8 and err[1] <= 1 and np.allclose(conf.sum(axis=0), 1.0)
+    conf = np.ascontiguousarray(_confusion(1, 0.9))
+    assert L.test_code_B_MSDP(path, 5, 40, 1, 0, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == 0
+    assert err[0] >= 38
+    assert L.test_code_B_MSDP(path, 5, 40, 1, 1, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == -6
+    assert L.test_code_B_MSDP(path, 5, 40, 2, 0, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == -4

@@ -63,3 +63,43 @@ def test_two_rank_reduce_equals_single_rank(tmp_path):
         r = [frame_range(total, k, w) for k in range(w)]
         assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+class _FakeMonteCarlo:
+    """Stands in for ldpc_amd.MonteCarlo on the CPU: per-frame outcomes derived from the
+    numpy restatement of the device generator (frames keyed by their global index)."""
+
+    def run(self, nframes, channel, param, llr_dtype, max_iter, seed=1, first_frame=0):
+        sys.path.insert(0, ROOT)
+        from oracle import mc_frontend as ref
+        c = dict(frames=0, not_converged=0, undetected=0, bit_errors=0)
+        for f in range(first_frame, first_frame + nframes):
+            err, _ = ref.bsc_exact_pattern(64, param, seed, f)
+            w = int(np.flatnonzero(err)[0])
+            c["frames"] += 1
+            c["not_converged"] += w < 8
+            c["undetected"] += w == 9
+            c["bit_errors"] += w
+        return c
+
+
+def _mc_worker(rank, world, port, total, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ldpc_amd.sharding import run_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = run_sharded(_FakeMonteCarlo(), total, 0, 0.1, 2, 10, seed=5)
+    if rank == 0:
+        np.save(out, np.array([c[k] for k in ("frames", "not_converged", "undetected", "bit_errors")]))
+    dist.destroy_process_group()
+
+
+def test_run_sharded_two_ranks_equals_one(tmp_path):
+    total = 333
+    out = str(tmp_path / "m.npy")
+    mp.spawn(_mc_worker, args=(2, _free_port(), total, out), nprocs=2, join=True)
+    one = _FakeMonteCarlo().run(total, 0, 0.1, 2, 10, seed=5)
+    assert np.load(out).tolist() == [one[k] for k in ("frames", "not_converged", "undetected", "bit_errors")]
+    assert one["frames"] == total and 0 < one["not_converged"] < total
