@@ -615,7 +615,7 @@ struct FusedQ88Engine : Engine {
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     lds = (size_t)(n + FQ_NDUMMY + 4) * 4;
     wg_per_cu = (int)((160 * 1024) / lds);
-    if (wg_per_cu > 4) wg_per_cu = 4;
+    if (wg_per_cu > 16) wg_per_cu = 16;   // (16 wavefronts of 128 VGPRs fill a CU)
     if (wg_per_cu < 1) wg_per_cu = 1;
     // Workgroup shape.  First choice: the register-cached kernel (<= 3 checks per thread,
     // <= 16 waves per CU so that every wave gets 128 VGPRs); waves should own equal
@@ -648,7 +648,7 @@ struct FusedQ88Engine : Engine {
       use_reg = bestW > 0;
     }
     if (!use_reg) {
-      bestG = env_g >= 1 && env_g <= wg_per_cu ? env_g : wg_per_cu;
+      bestG = env_g >= 1 && env_g <= wg_per_cu ? env_g : std::min(wg_per_cu, 4);
       const int maxW = bestG >= 2 ? 8 : 16;
       for (int W = maxW; W >= 1; W--) {
         if (env_w && W != env_w) continue;
