@@ -230,7 +230,10 @@ struct BinaryEngine : Engine {
     //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA
     cn_variant = o.cn_variant;
     if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) cn_variant = atoi(e);
-    if (cn_variant == 0) cn_variant = 1;
+    // measured on PEG-16000 (tools/bench_codes.py): the reload kernel wins for min-sum in
+    // 16/32-bit and for the float sum-product (+48 %), the DMA-staged one for the table
+    // sum-product and binary64 min-sum
+    if (cn_variant == 0) cn_variant = (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 : 2;
     const size_t lds_need = (size_t)rmax * 1024;
     if ((cn_variant == 1 || cn_variant == 4) && lds_need > 160 * 1024) cn_variant = 2;
     if (cn_variant == 3 && (rmax > 32 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 1;

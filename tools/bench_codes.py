@@ -3,7 +3,7 @@
 headline benchmark -- that is bench.py).  Frames resident in HBM, 10 iterations, no early
 exit, BSC-like LLRs above threshold so that every frame runs all iterations.
 
-  python tools/bench_codes.py > gpurun_out/bench_codes.txt
+  python tools/bench_codes.py [code-substring [alg-substring]] > gpurun_out/bench_codes.txt
 """
 import math
 import os
@@ -27,6 +27,10 @@ def main():
     algs = [("MINSUM_Q88", DT.I16, torch.int16), ("MINSUM_F32", DT.F32, torch.float32),
             ("MINSUM_F64", DT.F64, torch.float64), ("SPA_F32", DT.F32, torch.float32),
             ("SPA_TABLE_Q14", DT.I32, torch.int32)]
+    want_code = sys.argv[1] if len(sys.argv) > 1 else ""
+    want_alg = sys.argv[2] if len(sys.argv) > 2 else ""
+    rows = [r for r in rows if want_code in r[0]]
+    algs = [a for a in algs if want_alg in a[0]]
     print(f"{'code':24s} {'alg':14s} {'frames':>7s} {'ms/pass':>9s} {'info Gbit/s':>12s}")
     for name, p in rows:
         code = ldpc_amd.Code.from_alist(os.path.join(CODES, name))
