@@ -473,6 +473,9 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < NA; r++) {
+          // the masks keep slot 32w + j of word w in bit 31 - j: a last word with fewer than 32
+          // slots has been shifted in from the right and is moved up
+          if constexpr (NW > 1 && RM % 32 != 0) sg[r][NW - 1] <<= 32 - RM % 32;
           const unsigned p = pp[r] >> 31;
           par[r] = (int)p;
           bad |= (int)p ^ sbit[r];

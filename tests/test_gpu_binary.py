@@ -172,3 +172,45 @@ def test_every_check_node_kernel_is_bit_exact(hip, oracle, name, F, p, it, varia
         ref = run_oracle(oracle.dec_spa_table, oc, q14, s, it)
         dec = hip.Decoder(code, hip.ALG.SPA_TABLE_Q14, max_frames=256, early_exit=True, cn_variant=variant)
         check_exact(dec.decode(q14, su, it), ref, f"table cn_variant {variant} {name}")
+
+
+def _random_code(rng, n, m, dv):
+    """Random H with column weight dv (rows filled as evenly as a random fill allows, no
+    duplicate entries, every row weight >= 2)."""
+    H = np.zeros((m, n), np.uint8)
+    load = np.zeros(m, np.int64)
+    for v in range(n):
+        order = np.lexsort((rng.random(m), load))          # lightest rows first, random ties
+        rows = order[:dv]
+        H[rows, v] = 1
+        load[rows] += 1
+    assert (H.sum(axis=1) >= 2).all()
+    return H
+
+
+@pytest.mark.parametrize("n,m,dv,it", [(96, 48, 3, 10), (520, 130, 3, 12), (2000, 200, 3, 8), (3000, 150, 3, 8),
+                                       (1200, 1150, 3, 15), (4000, 1000, 4, 8), (777, 259, 5, 10), (6000, 300, 2, 6),
+                                       (2044, 1022, 6, 10)])
+def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
+    """The fused decoder picks a kernel per (slots per check, checks per thread, address width):
+    random codes of many shapes walk through those instantiations -- row weights 3 to 60, one
+    to three checks per thread, n not a multiple of 8 -- each bit-exact against the oracle,
+    with non-zero syndromes and a mix of converging and failing frames."""
+    rng = np.random.default_rng(n * 7 + m)
+    H = _random_code(rng, n, m, dv)
+    path = str(tmp_path / "rand.alist")
+    hip.alist.matrix_to_alist(H, path)
+    oc = oracle.load(path)
+    code = hip.Code.from_alist(path)
+    assert (code.n, code.m, code.E) == (n, m, n * dv)
+    F = 24
+    p = {2: 0.004, 3: 0.02, 4: 0.03, 5: 0.04, 6: 0.05}[dv] * (0.5 if n / m > 5 else 1.0)
+    x, s, llr = make_frames(oracle, oc, F, p, 5, "bsc")
+    q, raw = to_q88(llr)
+    ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q, s, it)
+    dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=16, early_exit=True, want_llr=True)
+    out = dec.decode(raw, s.astype(np.uint8), it, want=("bits", "iters", "synd", "status", "llr"))
+    check_exact(out, ref, f"random {n}x{m} dv={dv}")
+    nc = ref[3] != 0
+    if nc.any():
+        assert np.array_equal(out["llr"][nc].astype(np.float64), ref[4][nc])
