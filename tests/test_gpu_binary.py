@@ -190,12 +190,13 @@ def _random_code(rng, n, m, dv):
 
 @pytest.mark.parametrize("n,m,dv,it", [(96, 48, 3, 10), (520, 130, 3, 12), (2000, 200, 3, 8), (3000, 150, 3, 8),
                                        (1200, 1150, 3, 15), (4000, 1000, 4, 8), (777, 259, 5, 10), (6000, 300, 2, 6),
-                                       (2044, 1022, 6, 10)])
+                                       (2044, 1022, 6, 10), (6000, 4000, 3, 10), (5000, 3300, 2, 6)])
 def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
     """The fused decoder picks a kernel per (slots per check, checks per thread, address width):
     random codes of many shapes walk through those instantiations -- row weights 3 to 60, one
-    to three checks per thread, n not a multiple of 8 -- each bit-exact against the oracle,
-    with non-zero syndromes and a mix of converging and failing frames."""
+    to three checks per thread, n not a multiple of 8, and (m > 3072) the generic kernel with
+    four and more checks per thread -- each bit-exact against the oracle, with non-zero
+    syndromes and a mix of converging and failing frames; every input type is fed once."""
     rng = np.random.default_rng(n * 7 + m)
     H = _random_code(rng, n, m, dv)
     path = str(tmp_path / "rand.alist")
@@ -214,3 +215,5 @@ def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
     nc = ref[3] != 0
     if nc.any():
         assert np.array_equal(out["llr"][nc].astype(np.float64), ref[4][nc])
+    for inp in (raw.astype(np.int32), q.astype(np.float32), llr.astype(np.float64)):
+        check_exact(dec.decode(inp, s.astype(np.uint8), it), ref, f"random {n}x{m} dv={dv} {inp.dtype}")
