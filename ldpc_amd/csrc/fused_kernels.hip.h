@@ -461,7 +461,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             for (int r = 0; r < NA; r++) {
               const int k = kc + j;
               if (k >= RM) continue;
-              pp[r] ^= (unsigned)S[r][j];
+              // hard-decision parity, two slots per v_bitop3 (x ^ y ^ z); CH and RM are even
+              if ((j & 1) == 0) pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
               const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
               const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
               orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
