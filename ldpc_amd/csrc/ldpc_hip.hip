@@ -597,6 +597,18 @@ struct FusedQ88Engine : Engine {
   }
   size_t llr_elems_per_frame() const override { return (size_t)n; }
 
+  // Is there a register-cached kernel for this code (some split into wavefronts whose state
+  // fits the register file)?  Without one the generic fused kernel re-reads the indices from
+  // L2 every iteration and the two-pass HBM engine is faster (32000.2240.3.105: 13.9 against
+  // 7.8 Gbit/s), so the decoder only goes fused when this holds.
+  static bool reg_kernel_available(const ldpc_code &c) {
+    if (c.rmax > 64) return false;
+    const int need = (c.m + 63) / 64, r2 = fq_round_r2((c.rmax + 1) / 2);
+    for (int W = 1; W <= 16; W++)
+      if (fq_reg_shape_ok((need + W - 1) / W, r2)) return true;
+    return false;
+  }
+
   template <typename MaskT>
   static void (*pick(int cpt))(FusedArgs) {
     switch (cpt) {
@@ -788,10 +800,14 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
     case LDPC_ALG_MINSUM_F64: if (binary) d->eng.reset(new BinaryEngine<double, ALG_MS>); break;
     case LDPC_ALG_MINSUM_Q88:
       if (binary) {
-        // cn_variant 0: frame-resident fused kernel when the code fits in LDS;
-        // any other value (or LDPC_HIP_FUSED=0) selects the two-pass HBM engine
+        // cn_variant 0: frame-resident fused kernel when the code fits in LDS and a
+        // register-cached kernel exists for its shape; any other value (or
+        // LDPC_HIP_FUSED=0) selects the two-pass HBM engine
+        // (LDPC_HIP_FUSED=2 also allows the generic fused kernel where no register-cached one exists)
         bool fused = opts->cn_variant == 0 && FusedQ88Engine::fits(*c);
-        if (const char *e = getenv("LDPC_HIP_FUSED")) fused = fused && atoi(e) != 0;
+        const char *fe = getenv("LDPC_HIP_FUSED");
+        const int fmode = fe ? atoi(fe) : 1;
+        fused = fused && fmode != 0 && (fmode == 2 || FusedQ88Engine::reg_kernel_available(*c));
         if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which
         // does not fit an int16 Q8.8 message: such codes use int32 messages

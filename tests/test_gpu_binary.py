@@ -209,7 +209,12 @@ def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
     x, s, llr = make_frames(oracle, oc, F, p, 5, "bsc")
     q, raw = to_q88(llr)
     ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q, s, it)
-    dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=16, early_exit=True, want_llr=True)
+    import os
+    os.environ["LDPC_HIP_FUSED"] = "2"                # fused even where only the generic kernel exists
+    try:
+        dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=16, early_exit=True, want_llr=True)
+    finally:
+        del os.environ["LDPC_HIP_FUSED"]
     out = dec.decode(raw, s.astype(np.uint8), it, want=("bits", "iters", "synd", "status", "llr"))
     check_exact(out, ref, f"random {n}x{m} dv={dv}")
     nc = ref[3] != 0
@@ -217,3 +222,6 @@ def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
         assert np.array_equal(out["llr"][nc].astype(np.float64), ref[4][nc])
     for inp in (raw.astype(np.int32), q.astype(np.float32), llr.astype(np.float64)):
         check_exact(dec.decode(inp, s.astype(np.uint8), it), ref, f"random {n}x{m} dv={dv} {inp.dtype}")
+    # the default choice for this shape (two-pass engine where no register-cached kernel exists)
+    dflt = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=16, early_exit=True)
+    check_exact(dflt.decode(raw, s.astype(np.uint8), it), ref, f"random {n}x{m} dv={dv} default engine")
