@@ -422,6 +422,72 @@ __global__ __launch_bounds__(256) void cn_reload_kernel(
   if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
 }
 
+// Single-read variant for min-sum (row weights <= 64): the first sweep keeps, per frame,
+// min1, min2, WHICH row gave min1 and one sign bit per row; the outputs then follow from
+// that state alone (+-min2 on the arg-min row, +-min1 elsewhere; equal minima give the same
+// values whichever of them is named), so the second sweep only writes.  Traffic is exactly
+// the algorithmic 2*E*b per frame and iteration.
+template <typename T, int ALG>
+__global__ __launch_bounds__(256) void cn_single_read_kernel(
+    Graph g, int nslab, typename MT<T>::vec *__restrict__ msg,
+    const uint8_t *__restrict__ hard, const uint8_t *__restrict__ synd,
+    uint32_t *__restrict__ fail, Tables tab) {
+  typedef typename MT<T>::vec vec;
+  typedef typename MT<T>::acc acc;
+  constexpr int V = MT<T>::V;
+  static_assert(ALG == ALG_MS || ALG == ALG_MSQ, "single-read variant is min-sum only");
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int nw = (int)((gridDim.x * blockDim.x) >> 6);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = nw / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;
+  const acc big = ALG == ALG_MSQ ? (acc)Q88_CAP200 : (acc)200;
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb, sg = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    acc m1[V], m2[V];
+    int arg[V];
+    unsigned long long neg[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) { m1[v] = big; m2[v] = big; arg[v] = -1; neg[v] = 0; }
+    for (int k = 0; k < dc; k++) {
+      const vec x = rows[(size_t)k * 64];
+      par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc xv = (acc)x[v];
+        const bool ng = xv < 0;
+        const acc a = ng ? -xv : xv;
+        neg[v] |= (unsigned long long)(ng ? 1u : 0u) << k;
+        sg ^= (ng ? 1u : 0u) << v;
+        const acc hi = a > m1[v] ? a : m1[v];
+        m2[v] = hi < m2[v] ? hi : m2[v];
+        if (a < m1[v]) { m1[v] = a; arg[v] = k; }
+      }
+    }
+    failacc |= par;
+    for (int k = 0; k < dc; k++) {
+      vec o;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const acc mag = k == arg[v] ? m2[v] : m1[v];
+        const bool ng = ((neg[v] >> k) & 1ull) != 0;
+        const bool flip = (((sg >> v) & 1u) != 0) != ng;   // sgnprod != Sgntin[j][k]
+        o[v] = (T)(flip ? -mag : mag);
+      }
+      rows[(size_t)k * 64] = o;
+    }
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
 // Register-resident variant for row weights <= RB: the whole check lives in
 // VGPRs between the load and the store (no LDS, no second read).
 template <typename T, int ALG, int RB>

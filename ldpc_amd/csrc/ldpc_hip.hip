@@ -227,16 +227,19 @@ struct BinaryEngine : Engine {
 
     // check-node kernel selection
     //   0 auto, 1 LDS staged through registers, 2 two-pass reload, 3 register
-    //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA
+    //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA, 5 single read
+    //   with compressed per-frame state (min-sum, rmax <= 64)
     cn_variant = o.cn_variant;
     if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) cn_variant = atoi(e);
-    // measured on PEG-16000 (tools/bench_codes.py): the reload kernel wins for min-sum in
-    // 16/32-bit and for the float sum-product (+48 %), the DMA-staged one for the table
-    // sum-product and binary64 min-sum
-    if (cn_variant == 0) cn_variant = (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 : 2;
+    // measured on PEG-16000 (tools/bench_codes.py): the single-read kernel wins for min-sum
+    // (+11 % over the reload kernel), the reload kernel for the float sum-product (+48 % over
+    // the LDS-staged one), the DMA-staged one for the table sum-product
+    if (cn_variant == 0)
+      cn_variant = ((ALG == ALG_MS || ALG == ALG_MSQ) && rmax <= 64) ? 5 : (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 : 2;
     const size_t lds_need = (size_t)rmax * 1024;
     if ((cn_variant == 1 || cn_variant == 4) && lds_need > 160 * 1024) cn_variant = 2;
     if (cn_variant == 3 && (rmax > 32 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 1;
+    if (cn_variant == 5 && (rmax > 64 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 2;
     if (cn_variant == 1 && lds_need > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void *)cn_kernel<T, ALG, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
@@ -323,6 +326,13 @@ struct BinaryEngine : Engine {
                              hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
       }
       LAUNCHCHK("cn_reg_kernel");
+      return LDPC_OK;
+    }
+    if (cn_variant == 5) {
+      if constexpr (ALG == ALG_MS || ALG == ALG_MSQ)
+        hipLaunchKernelGGL((cn_single_read_kernel<T, ALG>), grid, block, 0, st, g, nslab, msg.as<vec>(),
+                           hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
+      LAUNCHCHK("cn_single_read_kernel");
       return LDPC_OK;
     }
     hipLaunchKernelGGL((cn_reload_kernel<T, ALG>), grid, block, 0, st, g, nslab, msg.as<vec>(),

@@ -149,12 +149,12 @@ def test_spa_table(hip, oracle, name, F, p, sigma, it):
     check_exact(dec.decode(llr, s.astype(np.uint8), it), ref, f"tab {name} f64")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("name,F,p,it", [("204.33.484.txt", 200, 0.05, 15), ("peg_16000_3_0.9.txt", 9, 0.0015, 8),
                                          ("Frolov_1024_0.5.txt", 40, 0.045, 20)])
 def test_every_check_node_kernel_is_bit_exact(hip, oracle, name, F, p, it, variant):
     """The two-pass engine's check-node kernels (opts.cn_variant 1 LDS staged, 2 reload,
-    3 register resident, 4 DMA staged; 0 = the measured best per algorithm) all give the
+    3 register resident, 4 DMA staged, 5 single read; 0 = the measured best per algorithm) all give the
     reference's results: Q8.8 (non-fused path), binary64 min-sum and the table sum-product."""
     oc = oracle.load(code_path(name))
     x, s, llr = make_frames(oracle, oc, F, p, 23, "bsc")
@@ -167,7 +167,7 @@ def test_every_check_node_kernel_is_bit_exact(hip, oracle, name, F, p, it, varia
     ref = run_oracle(oracle.dec_minsum, oc, llr, s, it)
     dec = hip.Decoder(code, hip.ALG.MINSUM_F64, max_frames=256, early_exit=False, cn_variant=variant)
     check_exact(dec.decode(llr.astype(np.float64), su, it), ref, f"f64 cn_variant {variant} {name}")
-    if variant != 3:                                  # (the register-resident kernel is min-sum only)
+    if variant not in (3, 5):                         # (those two kernels are min-sum only)
         q14 = oracle.float2fix14(llr)
         ref = run_oracle(oracle.dec_spa_table, oc, q14, s, it)
         dec = hip.Decoder(code, hip.ALG.SPA_TABLE_Q14, max_frames=256, early_exit=True, cn_variant=variant)
