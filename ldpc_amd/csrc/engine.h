@@ -119,3 +119,6 @@ int ldpc_gf_mul_host(int q, int a, int b);
 
 // gf_engine.hip
 Engine *ldpc_make_gf_engine(int alg, const ldpc_code &c);
+// fused_float.hip: frame-resident floating-point min-sum (prec 4: binary32, 8: binary64);
+// nullptr when the code does not fit in LDS
+Engine *ldpc_make_fused_float_engine(int prec, const ldpc_code &c);

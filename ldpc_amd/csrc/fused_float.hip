@@ -1,0 +1,378 @@
+// fused_float.hip -- whole-decode kernel of the floating-point min-sum decoder
+// (dec() of test_code_min_sum_B.c:137-208, binary64 as the reference computes or its
+// binary32 twin) with the frame resident in LDS.
+//
+// The Q8.8 fused kernel (fused_kernels.hip.h) folds message differences into the
+// posterior sums with integer LDS atomics; floating-point sums are not associative, and
+// the reference adds a variable's messages in column-slot order (:146-148), so here the
+// sums are rebuilt every iteration, in that order, by a variable pass:
+//
+//   LDS   q0[n], sum[n]                channel LLR and posterior of every variable
+//         per check: min1, min2, slot of min1, one sign bit per slot   (its c2v messages,
+//         compressed: c2v of slot k is +-min1, or +-min2 in the slot of min1 -- the minimum
+//         over "the others" of :168-176)
+//   VGPRs the same compressed state of the thread's own checks (previous iteration)
+//
+// One workgroup decodes one frame, start to finish.  Per iteration:
+//   check pass     each check thread walks its slots: S = sum[v], rebuilds its own previous
+//                  message c_old, v2c = S - c_old (:150), sign parity with the syndrome bit
+//                  (:163-166) and min1/min2 of |v2c| (cap 200, :169) -> new compressed
+//                  state to LDS.  sign(S) over the slots is the syndrome of the hard
+//                  decisions after the previous iteration (enc() + HamDist, :200-203).
+//   barrier        (__syncthreads_or: the exit test)
+//   variable pass  each variable thread rebuilds sum = q0 + c2v_0 + c2v_1 + ... in slot
+//                  order from the compressed check states (:146-148, :190-193).
+//   barrier
+// Every floating-point operation is the reference's, on the same operands in the same
+// order, so decoded bits, iteration counts, syndromes and posteriors are bit-identical
+// (binary64: to the reference; binary32: to its binary32 twin).  sum is stored as
+// sum + 0.0 (turns -0.0 into +0.0, nothing else): then "sum < 0" is its sign bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "engine.h"
+#include "lds_schedule.h"
+
+namespace ldpc {
+
+struct FfArgs {
+  const uint16_t *colT;    // [rounds][RM][block]  LDS word of (check = round*block + tid, slot)
+  const uint32_t *realT;   // [rounds][block][NW]  bit k of word k/32: slot k holds an edge
+  const uint32_t *vtab;    // [cmax][var_words]    (check << 8) | slot of the variable's kk-th edge; check == m: none
+  const uint16_t *pos;     // [n] variable -> LDS word
+  int n, m, RM, rounds, cmax;
+  int var_words, words, dummy_base;
+  int nframes, max_iter;
+  const void *llr;         // [nframes][n] binary64 (dt 0) or binary32 (dt 1), frame-major
+  int dt;
+  const uint8_t *synd;     // [nframes][m] or null
+  uint8_t *bits;           // [nframes][n] or null
+  int32_t *iters;          // [nframes] or null
+  uint8_t *sout;           // [nframes][m] or null
+  int32_t *status;         // [nframes] or null
+  float *llr_out;          // [nframes][n] or null
+  int *counter;            // frame queue head (zeroed by the host before the launch)
+};
+
+#define FF_NDUMMY 64
+#define FF_CAP 200          /* min_msg starts at 200 (test_code_min_sum_B.c:169) */
+
+template <int NW> struct FfSgw { static constexpr int value = NW == 1 ? 2 : 4; };
+
+template <typename T, int CPT, int NW>
+__global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ff_lds[];
+  constexpr int SGW = FfSgw<NW>::value;        // words of sign/arg state per check
+  T *sumL = (T *)ff_lds;
+  T *q0L = sumL + a.words;
+  T *magL = q0L + a.var_words;                 // [m + 1][2]  min1, min2
+  uint32_t *sgL = (uint32_t *)(magL + 2 * (a.m + 1));   // [m + 1][SGW]  sign words, slot of min1
+  int *frame_slot = (int *)(sgL + SGW * (a.m + 1));
+  const int tid = threadIdx.x, B = blockDim.x;
+  const T BIG = (T)1e30;
+
+  bool has[CPT];
+  uint32_t real[CPT][NW];
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    has[r] = r < a.rounds && r * B + tid < a.m;
+#pragma unroll
+    for (int w = 0; w < NW; w++) real[r][w] = has[r] ? a.realT[((size_t)r * B + tid) * NW + w] : 0u;
+  }
+  // constants of the workgroup's life: pad slots read +BIG (sign 0, never a minimum), words
+  // that hold no variable, and the "no edge" check state whose message is -0.0 (x + -0.0 = x)
+  for (int i = a.dummy_base + tid; i < a.words; i += B) sumL[i] = BIG;
+  for (int i = tid; i < a.var_words; i += B) { q0L[i] = (T)0; sumL[i] = (T)0; }
+  if (tid == 0) {
+    magL[2 * a.m] = (T)0; magL[2 * a.m + 1] = (T)0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sgL[SGW * a.m + w] = 1u;
+    sgL[SGW * a.m + NW] = 1u;
+    *frame_slot = atomicAdd(a.counter, 1);
+  }
+  __syncthreads();
+
+  for (;;) {
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+    int next_frame = 0;
+    if (tid == 0) next_frame = atomicAdd(a.counter, 1);   // its round trip hides under the decoding
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 1) {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) { const T x = (T)p[i]; const int w = a.pos[i]; q0L[w] = x; sumL[w] = x + (T)0; }
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) { const T x = (T)p[i]; const int w = a.pos[i]; q0L[w] = x; sumL[w] = x + (T)0; }
+      }
+    }
+    // compressed messages of the thread's checks as of the previous iteration (all +0.0: :141)
+    T om1[CPT], om2[CPT];
+    uint32_t oarg[CPT], osg[CPT][NW];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      om1[r] = om2[r] = (T)0;
+      oarg[r] = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) osg[r][w] = 0;
+      sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
+      par[r] = 0;
+    }
+    __syncthreads();
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      // ---- check pass on the sums of iteration t-1
+      int bad = 0;
+#pragma unroll
+      for (int r = 0; r < CPT; r++) {
+        if (has[r]) {
+          const uint16_t *col = a.colT + (size_t)r * a.RM * B + tid;
+          T m1 = (T)FF_CAP, m2 = (T)FF_CAP;
+          uint32_t arg = 0, p = 0, sg[NW];
+#pragma unroll
+          for (int w = 0; w < NW; w++) sg[w] = 0;
+          for (int k = 0; k < a.RM; k++) {
+            const T S = sumL[col[(size_t)k * B]];
+            p ^= (uint32_t)(S < (T)0);
+            T co = ((uint32_t)k == oarg[r]) ? om2[r] : om1[r];
+            if ((osg[r][NW == 1 ? 0 : (k >> 5)] >> (k & 31)) & 1u) co = -co;
+            const T q = S - co;                                   // :150
+            const T mag = q < (T)0 ? -q : q;
+            if (q < (T)0) sg[NW == 1 ? 0 : (k >> 5)] |= 1u << (k & 31);
+            if (mag < m1) { m2 = m1; m1 = mag; arg = (uint32_t)k; }
+            else if (mag < m2) { m2 = mag; }
+          }
+          par[r] = (int)p;
+          bad |= (int)p ^ sbit[r];
+          // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:177-178)
+          uint32_t tot = (uint32_t)sbit[r];
+#pragma unroll
+          for (int w = 0; w < NW; w++) tot ^= (uint32_t)__popc(sg[w]);
+          const int j = r * B + tid;
+          magL[2 * j] = m1; magL[2 * j + 1] = m2;
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            osg[r][w] = (tot & 1u) ? (sg[w] ^ real[r][w]) : sg[w];
+            sgL[SGW * j + w] = osg[r][w];
+          }
+          sgL[SGW * j + NW] = arg;
+          om1[r] = m1; om2[r] = m2; oarg[r] = arg;
+        }
+      }
+      const int any_bad = __syncthreads_or(bad);
+      // the reference tests H*bits == s after each iteration (:200-203), not before the first
+      if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      // ---- variable pass: sum = q0 + c2v in column-slot order (:146-148)
+      for (int w = tid; w < a.var_words; w += B) {
+        T sum = q0L[w];
+        for (int kk = 0; kk < a.cmax; kk++) {
+          const uint32_t e = a.vtab[(size_t)kk * a.var_words + w];
+          const int j = (int)(e >> 8), p = (int)(e & 0xffu);
+          const uint32_t sw = sgL[SGW * j + (NW == 1 ? 0 : (p >> 5))];
+          const uint32_t arg = sgL[SGW * j + NW];
+          const T mg = magL[2 * j + (arg == (uint32_t)p ? 1 : 0)];
+          sum = sum + (((sw >> (p & 31)) & 1u) ? -mg : mg);
+        }
+        sumL[w] = sum + (T)0;
+      }
+      __syncthreads();
+    }
+
+    if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = sumL[a.pos[i]] < (T)0;     // :194-195
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = (float)sumL[a.pos[i]];
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (has[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+    __syncthreads();                           // everyone has read this frame's number and its sums
+    if (tid == 0) *frame_slot = next_frame;
+    // publication barrier in line after the write (see fused_kernels.hip.h: at the loop head the
+    // compiler dropped the wait between this ds_write and the barrier across the back edge)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+namespace {
+
+typedef void (*FfKern)(FfArgs);
+
+template <typename T, int NW>
+FfKern ff_pick(int cpt) {
+  switch (cpt) {
+    case 1: return fused_ms_kernel<T, 1, NW>;
+    case 2: return fused_ms_kernel<T, 2, NW>;
+    case 3: return fused_ms_kernel<T, 3, NW>;
+    case 4: return fused_ms_kernel<T, 4, NW>;
+    case 5: case 6: return fused_ms_kernel<T, 6, NW>;
+    case 7: case 8: return fused_ms_kernel<T, 8, NW>;
+  }
+  return nullptr;
+}
+
+template <typename T>
+struct FusedFloatEngine : Engine {
+  ldpc_opts opts{};
+  int n = 0, m = 0, rmax = 0, cmax = 0, RM = 0, NW = 1;
+  int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
+  size_t lds = 0;
+  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter;
+  LdsSchedule sched;
+  FfKern kern = nullptr;
+
+  static size_t lds_bytes(int words, int var_words, int m, int nw) {
+    const int sgw = nw == 1 ? 2 : 4;
+    return sizeof(T) * ((size_t)words + var_words + 2 * (size_t)(m + 1)) + 4 * (size_t)sgw * (m + 1) + 16;
+  }
+  // (the schedule may leave a few words of slack per bank: n + 64 bounds var_words closely enough
+  // for a first test; init() checks the real figure)
+  static bool fits(const ldpc_code &c) {
+    if (c.q != 2 || c.n > 65000 || c.rmax > 64 || c.rmax < 1 || c.cmax > 32 || c.m > 8192) return false;
+    const int nw = (2 * ((c.rmax + 1) / 2) + 31) / 32;
+    return lds_bytes(c.n + 64 + FF_NDUMMY, c.n + 64, c.m, nw) + 1024 <= 160 * 1024;
+  }
+  size_t llr_elems_per_frame() const override { return (size_t)n; }
+
+  int init(const ldpc_code &c, const ldpc_opts &o) override {
+    opts = o;
+    n = c.n; m = c.m; rmax = c.rmax; cmax = c.cmax;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, o.device));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    RM = std::max(2, 2 * ((rmax + 1) / 2));
+    NW = (RM + 31) / 32;
+    // workgroup shape: up to 16 wavefronts, every wavefront with the same number of checks
+    const int need = (m + 63) / 64;
+    int W = std::min(16, need);
+    rounds = (need + W - 1) / W;
+    if (rounds > 8) { ldpc_set_error("fused min-sum: too many checks"); return LDPC_ERR_UNSUPPORTED; }
+    W = (need + rounds - 1) / rounds;
+    if (const char *e = getenv("LDPC_HIP_FUSED_WAVES")) {
+      const int w = atoi(e);
+      if (w >= 1 && w <= 16 && (need + w - 1) / w <= 8) { W = w; rounds = (need + W - 1) / W; }
+    }
+    block = W * 64;
+    int optimise = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
+    if (ldpc_build_lds_schedule(c, block, RM, FF_NDUMMY, optimise != 0, sched)) {
+      ldpc_set_error("LDS schedule: code too large");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+    rounds = sched.rounds;
+    lds = lds_bytes(sched.words, sched.var_words, m, NW);
+    if (lds + 1024 > 160 * 1024) {
+      ldpc_set_error("fused min-sum: frame does not fit in LDS");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+    wg_per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)std::max(1, 16 / W));
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_WG_PER_CU")) {
+      const int g = atoi(e);
+      if (g >= 1 && (size_t)g * (lds + 512) <= 160 * 1024) wg_per_cu = g;
+    }
+    kern = NW == 1 ? ff_pick<T, 1>(rounds) : ff_pick<T, 2>(rounds);
+    if (!kern) { ldpc_set_error("no fused min-sum kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
+
+    // which slots hold edges (bit k of word k / 32), and where each edge of each variable sits
+    std::vector<uint32_t> realT((size_t)rounds * block * NW, 0u);
+    std::vector<int> slot_of_edge(c.E(), -1);
+    for (int j = 0; j < m; j++) {
+      const int r = j / block, t = j % block;
+      for (int k = 0; k < RM; k++) {
+        const int w = sched.colT[((size_t)r * RM + k) * block + t];
+        if (w >= sched.dummy_base) continue;
+        realT[((size_t)r * block + t) * NW + k / 32] |= 1u << (k % 32);
+        for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++)
+          if (sched.pos[c.col_idx[e]] == w) slot_of_edge[e] = k;
+      }
+    }
+    std::vector<int> row_of(c.E());
+    for (int j = 0; j < m; j++)
+      for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
+    std::vector<uint32_t> vtab((size_t)std::max(1, cmax) * sched.var_words, (uint32_t)m << 8);
+    for (int v = 0; v < n; v++)
+      for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++) {
+        const int e = c.edge_of[c.col_ptr[v] + kk];
+        if (slot_of_edge[e] < 0) { ldpc_set_error("fused min-sum: schedule lost an edge"); return LDPC_ERR_FORMAT; }
+        vtab[(size_t)kk * sched.var_words + sched.pos[v]] = ((uint32_t)row_of[e] << 8) | (uint32_t)slot_of_edge[e];
+      }
+    int rc;
+    if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
+    if ((rc = d_realT.ensure(realT.size() * 4))) return rc;
+    if ((rc = d_vtab.ensure(vtab.size() * 4))) return rc;
+    if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
+    if ((rc = d_counter.ensure(256))) return rc;
+    HIPCHK(hipMemcpy(d_colT.p, sched.colT.data(), sched.colT.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_realT.p, realT.data(), realT.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_vtab.p, vtab.data(), vtab.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_pos.p, sched.pos.data(), sched.pos.size() * 2, hipMemcpyHostToDevice));
+    if (lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return LDPC_OK;
+  }
+
+  int decode(int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter, uint8_t *bits,
+             int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out, hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
+    if (!llr || max_iter < 0 || max_iter > 65000) {
+      ldpc_set_error("nframes/max_iter out of range for this decoder");
+      return LDPC_ERR_ARG;
+    }
+    if (dt != LDPC_DT_F64 && dt != LDPC_DT_F32) {
+      ldpc_set_error("floating-point min-sum takes F64 or F32 input");
+      return LDPC_ERR_ARG;
+    }
+    if (llr_out && !opts.want_llr) {
+      ldpc_set_error("llr_out needs opts.want_llr");
+      return LDPC_ERR_ARG;
+    }
+    HIPCHK(hipMemsetAsync(d_counter.p, 0, 4, st));
+    FfArgs a;
+    a.colT = d_colT.as<uint16_t>();
+    a.realT = d_realT.as<uint32_t>();
+    a.vtab = d_vtab.as<uint32_t>();
+    a.pos = d_pos.as<uint16_t>();
+    a.n = n; a.m = m; a.RM = RM; a.rounds = rounds; a.cmax = cmax;
+    a.var_words = sched.var_words; a.words = sched.words; a.dummy_base = sched.dummy_base;
+    a.nframes = nframes; a.max_iter = max_iter;
+    a.llr = llr; a.dt = dt; a.synd = sy;
+    a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
+    a.counter = d_counter.as<int>();
+    long grid = (long)num_cu * wg_per_cu;
+    if (grid > nframes) grid = nframes;
+    prof_begin(K_FUSED, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
+    LAUNCHCHK("fused_ms_kernel");
+    prof_end(st);
+    last_iterations = max_iter;
+    return LDPC_OK;
+  }
+};
+
+}  // namespace
+}  // namespace ldpc
+
+// prec: 4 binary32, 8 binary64.  nullptr: the code does not fit (the caller takes the two-pass engine)
+Engine *ldpc_make_fused_float_engine(int prec, const ldpc_code &c) {
+  if (prec == 4) return ldpc::FusedFloatEngine<float>::fits(c) ? new ldpc::FusedFloatEngine<float> : nullptr;
+  return ldpc::FusedFloatEngine<double>::fits(c) ? new ldpc::FusedFloatEngine<double> : nullptr;
+}

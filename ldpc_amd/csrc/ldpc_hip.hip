@@ -805,9 +805,24 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
   if (d->opts.max_frames <= 0) d->opts.max_frames = 4096;
   d->max_frames = d->opts.max_frames;
   const bool binary = c->q == 2;
+  const char *fe = getenv("LDPC_HIP_FUSED");
+  const int fmode = fe ? atoi(fe) : 1;
   switch (opts->alg) {
-    case LDPC_ALG_MINSUM_F32: if (binary) d->eng.reset(new BinaryEngine<float, ALG_MS>); break;
-    case LDPC_ALG_MINSUM_F64: if (binary) d->eng.reset(new BinaryEngine<double, ALG_MS>); break;
+    case LDPC_ALG_MINSUM_F32:
+    case LDPC_ALG_MINSUM_F64:
+      if (binary) {
+        // cn_variant 0: frame-resident fused kernel when the frame fits in LDS (fused_float.hip);
+        // any other value (or LDPC_HIP_FUSED=0) selects the two-pass HBM engine
+        const bool f32 = opts->alg == LDPC_ALG_MINSUM_F32;
+        if (opts->cn_variant == 0 && fmode != 0) {
+          d->eng.reset(ldpc_make_fused_float_engine(f32 ? 4 : 8, *c));
+          if (d->eng && d->eng->init(d->code, d->opts) != LDPC_OK) d->eng.reset();
+          if (d->eng) { *out = d.release(); return LDPC_OK; }
+        }
+        if (f32) d->eng.reset(new BinaryEngine<float, ALG_MS>);
+        else d->eng.reset(new BinaryEngine<double, ALG_MS>);
+      }
+      break;
     case LDPC_ALG_MINSUM_Q88:
       if (binary) {
         // cn_variant 0: frame-resident fused kernel when the code fits in LDS and a
@@ -815,8 +830,6 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
         // LDPC_HIP_FUSED=0) selects the two-pass HBM engine
         // (LDPC_HIP_FUSED=2 also allows the generic fused kernel where no register-cached one exists)
         bool fused = opts->cn_variant == 0 && FusedQ88Engine::fits(*c);
-        const char *fe = getenv("LDPC_HIP_FUSED");
-        const int fmode = fe ? atoi(fe) : 1;
         fused = fused && fmode != 0 && (fmode == 2 || FusedQ88Engine::reg_kernel_available(*c));
         if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which

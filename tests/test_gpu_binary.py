@@ -225,3 +225,54 @@ def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
     # the default choice for this shape (two-pass engine where no register-cached kernel exists)
     dflt = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=16, early_exit=True)
     check_exact(dflt.decode(raw, s.astype(np.uint8), it), ref, f"random {n}x{m} dv={dv} default engine")
+
+
+@pytest.mark.parametrize("n,m,dv,it", [(96, 48, 3, 10), (520, 130, 3, 12), (2000, 200, 3, 8), (3000, 150, 3, 8),
+                                       (1200, 1150, 3, 15), (4000, 1000, 4, 8), (777, 259, 5, 10), (6000, 300, 2, 6),
+                                       (2044, 1022, 6, 10), (6000, 4000, 3, 10)])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_fused_float_minsum_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it, prec):
+    """The frame-resident floating-point min-sum kernel (fused_float.hip) on random codes of many
+    shapes -- row weights 3 to 60 (one and two sign words), one to eight checks per thread, irregular
+    LDS placement -- bit-exact against the oracle in both precisions: bits, iteration counts,
+    syndromes, status, and the posterior sums of the frames that ran every iteration.  The
+    profile counters prove the fused kernel (not the two-pass engine) did the work."""
+    rng = np.random.default_rng(n * 11 + m)
+    H = _random_code(rng, n, m, dv)
+    path = str(tmp_path / "rand.alist")
+    hip.alist.matrix_to_alist(H, path)
+    oc = oracle.load(path)
+    code = hip.Code.from_alist(path)
+    F = 24
+    p = {2: 0.004, 3: 0.02, 4: 0.03, 5: 0.04, 6: 0.05}[dv] * (0.5 if n / m > 5 else 1.0)
+    dec = two = None
+    for kind in ("awgn", "bsc"):                      # distinct magnitudes / all magnitudes tied
+        x, s, llr = make_frames(oracle, oc, F, p, 6, kind, sigma=0.7 if n / m <= 5 else 0.45)
+        su = s.astype(np.uint8)
+        if prec == "f32":
+            inp = llr.astype(np.float32)
+            ref = run_oracle(oracle.dec_minsum_f32, oc, inp, s, it)
+            alg = hip.ALG.MINSUM_F32
+        else:
+            inp = llr.astype(np.float64)
+            ref = run_oracle(oracle.dec_minsum, oc, inp, s, it)
+            alg = hip.ALG.MINSUM_F64
+        dec = dec or hip.Decoder(code, alg, max_frames=16, want_llr=True)
+        dec.profile(True)
+        out = dec.decode(inp, su, it, want=("bits", "iters", "synd", "status", "llr"))
+        ms, cnt = dec.profile_read()
+        dec.profile(False)
+        # (a frame needs q0 and sum per variable plus the compressed check states in 160 KiB of LDS:
+        # 6000 x 4000 in binary64 does not fit and rightly takes the two-pass engine)
+        size = {"f32": 4, "f64": 8}[prec]
+        if size * (2 * n + 2 * m + 300) + 16 * m < 158 * 1024:
+            assert cnt[2] > 0 and cnt[0] == 0 and cnt[1] == 0, "the fused kernel did not run"
+        else:
+            assert cnt[2] == 0 and cnt[1] > 0
+        check_exact(out, ref, f"fused float {prec} {kind} random {n}x{m} dv={dv}")
+        nc = ref[3] != 0
+        if nc.any():
+            assert np.array_equal(out["llr"][nc], ref[4][nc].astype(np.float32))
+        # the two-pass engine (cn_variant != 0) must agree with it
+        two = two or hip.Decoder(code, alg, max_frames=16, cn_variant=2)
+        check_exact(two.decode(inp, su, it), ref, f"two-pass float {prec} {kind} random {n}x{m} dv={dv}")
