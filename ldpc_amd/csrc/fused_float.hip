@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "fused_kernels.hip.h"
 #include "lds_schedule.h"
 
 namespace ldpc {
@@ -56,6 +57,9 @@ struct FfArgs {
   int32_t *status;         // [nframes] or null
   float *llr_out;          // [nframes][n] or null
   int *counter;            // frame queue head (zeroed by the host before the launch)
+  // register-cached kernel only
+  const uint16_t *vtabT;   // [VPT*CM][block]  (check << 5) | shift of its sign bit, per (thread, variable, edge)
+  const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
 };
 
 #define FF_NDUMMY 64
@@ -212,6 +216,274 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Register-cached binary32 variant: the same algorithm with every index the workgroup needs
+// held in VGPRs for its (persistent) life -- the LDS addresses of each check's slots (two
+// 16-bit absolute byte addresses per register, as in fused_q88_reg_kernel) and, for the
+// variable pass, (check, sign-bit shift) of each edge of the thread's VPT variables (two
+// 16-bit entries per register) -- with all loops unrolled: an iteration touches no global
+// memory.  q0 of the thread's variables lives in registers as well.
+//   LDS   sum[words] binary32 (placed by the schedule compiler), then per check one 16-byte
+//         record {min1, min2, sign mask, slot of min1} read by the variable pass with one
+//         ds_read_b128 per edge.
+//   CPT checks per thread, R2 slot pairs per check (RM = 2*R2 <= 32: one sign word),
+//   VPT variables per thread, CM edges per variable (pads point at the "no edge" record).
+// Sign masks keep slot k at bit RM-1-k (shifted in with v_alignbit); an edge's entry holds
+// sh = 32-RM+k, so mask << sh puts its sign at bit 31, and the record stores the slot of min1
+// as 32-RM+k too.
+typedef unsigned ff_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ff_u4 lds_u4;
+typedef __attribute__((address_space(3))) float lds_float;
+
+template <int HI>
+__device__ __forceinline__ unsigned ff_rec_addr(unsigned stbase, unsigned packed) {
+  unsigned r;   // (entry >> 5) * 16 + stbase; volatile: not hoisted out of the iteration loop
+  if (HI) asm volatile("v_bfe_u32 %0, %1, 21, 11" : "=v"(r) : "v"(packed));
+  else asm volatile("v_bfe_u32 %0, %1, 5, 11" : "=v"(r) : "v"(packed));
+  return (r << 4) + stbase;
+}
+template <int HI>
+__device__ __forceinline__ unsigned ff_rec_shift(unsigned packed) {
+  unsigned r;
+  if (HI) asm volatile("v_bfe_u32 %0, %1, 16, 5" : "=v"(r) : "v"(packed));
+  else asm volatile("v_and_b32 %0, 31, %1" : "=v"(r) : "v"(packed));
+  return r;
+}
+
+template <int CPT, int R2, int VPT, int CM, int LB, int MINW>
+__global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ffsum[];   // [words] sums, records, frame id
+  constexpr int RM = 2 * R2;
+  static_assert(RM <= 32, "one sign word per check");
+  constexpr int CH = RM < 4 ? RM : 4;          // LDS reads in flight per check
+  constexpr int NE = VPT * CM, NE2 = (NE + 1) / 2;
+  constexpr int VCH = CM <= 4 ? 2 : 1;         // variables whose records are in flight together
+  constexpr int B = LB;                        // (the host launches exactly LB threads: variable w = tid + B*i
+  const int tid = threadIdx.x;                 //  is then an immediate offset, not an address register per variable)
+  const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)ffsum;
+  const unsigned stbase = lbase + (unsigned)a.words * 4u;
+  ff_u4 *rec = (ff_u4 *)(ffsum + a.words);     // [m + 1]
+  float *q0L = (float *)(rec + a.m + 1);       // [var_words] channel LLRs, by LDS word like the sums
+  int *frame_slot = (int *)(q0L + a.var_words);
+
+  bool has[CPT];
+  unsigned idx[CPT][R2], allm[CPT];
+  unsigned vidx[NE2];
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    has[r] = r < a.rounds && r * B + tid < a.m;
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) {
+      unsigned lo = (unsigned)a.dummy_base, hi = (unsigned)a.dummy_base;
+      if (r < a.rounds) {
+        const uint16_t *col = a.colT + (size_t)r * RM * B + tid;
+        lo = col[(size_t)(2 * k2) * B];
+        hi = col[(size_t)(2 * k2 + 1) * B];
+      }
+      lo = lo * 4u + lbase; hi = hi * 4u + lbase;    // absolute addresses (host: they fit 16 bits)
+      idx[r][k2] = lo | (hi << 16);
+      asm volatile("" : "+v"(idx[r][k2]));   // packed here, once (not re-packed per frame from 2*R2 halves)
+    }
+    allm[r] = r < a.rounds ? a.maskT[(size_t)r * B + tid] : 0u;
+  }
+#pragma unroll
+  for (int e2 = 0; e2 < NE2; e2++) {
+    const unsigned lo = a.vtabT[(size_t)(2 * e2) * B + tid];
+    const unsigned hi = 2 * e2 + 1 < NE ? a.vtabT[(size_t)(2 * e2 + 1) * B + tid] : ((unsigned)a.m << 5);
+    vidx[e2] = lo | (hi << 16);
+    asm volatile("" : "+v"(vidx[e2]));
+  }
+  const bool wave_full = __ballot(has[CPT - 1]) != 0;   // (wave-uniform) any check in the last round?
+
+  const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const fq_u4 *pos8 = (const fq_u4 *)a.pos;
+
+  for (int i = a.dummy_base + tid; i < a.words; i += B) ffsum[i] = 1e30f;     // pad slots: sign 0, never a minimum
+  for (int i = tid; i < a.var_words; i += B) { ffsum[i] = 0.0f; q0L[i] = 0.0f; }   // (words that hold no variable)
+  if (tid == 0) {
+    ff_u4 none; none.x = 0u; none.y = 0u; none.z = 0xffffffffu; none.w = 0xffffffffu;   // message -0.0
+    rec[a.m] = none;
+    *frame_slot = atomicAdd(a.counter, 1);
+  }
+  __syncthreads();
+  for (;;) {
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+    int next_frame = 0;
+    if (tid == 0) next_frame = atomicAdd(a.counter, 1);
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 1) {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) { const float x = __builtin_nontemporal_load(p + i) + 0.0f; const int w = a.pos[i]; ffsum[w] = x; q0L[w] = x; }
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) { const float x = (float)__builtin_nontemporal_load(p + i) + 0.0f; const int w = a.pos[i]; ffsum[w] = x; q0L[w] = x; }
+      }
+    }
+    float om1[CPT], om2[CPT];
+    unsigned oarg[CPT], osg[CPT];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      om1[r] = om2[r] = 0.0f;
+      oarg[r] = 0u; osg[r] = 0u;
+      sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
+      par[r] = 0;
+    }
+    __syncthreads();
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      int bad = 0;
+      auto check_pass = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+        float m1[CPT], m2[CPT];
+        unsigned arg[CPT], pp[CPT], sg[CPT], orot[CPT], oarot[CPT];
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          m1[r] = m2[r] = (float)FF_CAP;
+          arg[r] = 0u; pp[r] = 0u; sg[r] = 0u;
+          orot[r] = osg[r] << (32 - RM);           // old sign of the slot in turn: always bit 31
+          oarot[r] = 0x80000000u >> oarg[r];
+        }
+#pragma unroll
+        for (int kc = 0; kc < RM; kc += CH) {
+          int S[CPT][CH];
+#pragma unroll
+          for (int r = 0; r < NA; r++)
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+              const int k = kc + j;
+              if (k >= RM) continue;
+              S[r][j] = (k & 1) ? *fq_slot_ptr<1, 0>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, 0>(lbase, idx[r][k >> 1]);
+            }
+#pragma unroll
+          for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int r = 0; r < NA; r++) {
+              const int k = kc + j;
+              if (k >= RM) continue;
+              // parity of the hard decisions (sums are stored as sum + 0.0: sign bit <=> sum < 0)
+              if ((j & 1) == 0) pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
+              // old magnitude of this slot: min2 in the slot of min1 (its one-hot mask rotates with the signs)
+              const unsigned sel = (unsigned)((int)oarot[r] >> 31);
+              oarot[r] = fq_shl1(oarot[r]);
+              const float mo = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(om2[r]), __float_as_uint(om1[r]), 0xCA));
+              const float q = __int_as_float(S[r][j]) - __uint_as_float(FQ_ANDOR(orot[r], 0x80000000u, __float_as_uint(mo)));
+              orot[r] = fq_shl1(orot[r]);
+              sg[r] = __builtin_amdgcn_alignbit(sg[r], __float_as_uint(q), 31);
+              const float aq = __builtin_fabsf(q);
+              m2[r] = __builtin_amdgcn_fmed3f(m1[r], aq, m2[r]);
+              const bool lt = aq < m1[r];
+              arg[r] = lt ? (unsigned)k : arg[r];
+              m1[r] = lt ? aq : m1[r];
+            }
+          // the running values are materialised here: pure arithmetic is not ordered against
+          // sched_barrier when the block is first linearised, and a check's whole chain can end
+          // up after the last chunk with every sum it read still live
+#pragma unroll
+          for (int r = 0; r < NA; r++)
+            asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]), "+v"(orot[r]), "+v"(oarot[r]));
+          __builtin_amdgcn_sched_barrier(0);   // keeps a chunk's work in the chunk (live registers)
+        }
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          const unsigned p = pp[r] >> 31;
+          par[r] = (int)p;
+          bad |= has[r] ? ((int)p ^ sbit[r]) : 0;
+          const unsigned tot = (unsigned)sbit[r] ^ (unsigned)__popc(sg[r]);
+          osg[r] = (tot & 1u) ? (sg[r] ^ allm[r]) : sg[r];
+          om1[r] = m1[r]; om2[r] = m2[r]; oarg[r] = arg[r];
+          // materialise the compressed state now (see fused_q88_reg_kernel)
+          asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]), "+v"(osg[r]));
+          if (has[r]) {
+            ff_u4 st;
+            st.x = __float_as_uint(om1[r]); st.y = __float_as_uint(om2[r]);
+            st.z = osg[r]; st.w = oarg[r] + (unsigned)(32 - RM);
+            rec[r * B + tid] = st;
+          }
+        }
+      };
+      if (wave_full) check_pass(std::integral_constant<int, CPT>{});
+      else check_pass(std::integral_constant<int, CPT - 1>{});
+      const int any_bad = __syncthreads_or(bad);
+      if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      // ---- variable pass
+#pragma unroll
+      for (int i0 = 0; i0 < VPT; i0 += VCH) {
+        ff_u4 st[VCH][CM];
+#pragma unroll
+        for (int u = 0; u < VCH; u++)
+#pragma unroll
+          for (int kk = 0; kk < CM; kk++) {
+            const int i = i0 + u;
+            if (i >= VPT) continue;
+            const int e = i * CM + kk;
+            const unsigned ad = (e & 1) ? ff_rec_addr<1>(stbase, vidx[e >> 1]) : ff_rec_addr<0>(stbase, vidx[e >> 1]);
+            st[u][kk] = *(lds_u4 *)(unsigned long)ad;
+          }
+#pragma unroll
+        for (int u = 0; u < VCH; u++) {
+          const int i = i0 + u;
+          if (i >= VPT) continue;
+          const int w = tid + B * i;
+          float sum = (i < VPT - 2 || w < a.var_words) ? q0L[w] : 0.0f;
+#pragma unroll
+          for (int kk = 0; kk < CM; kk++) {
+            const int e = i * CM + kk;
+            const unsigned sh = (e & 1) ? ff_rec_shift<1>(vidx[e >> 1]) : ff_rec_shift<0>(vidx[e >> 1]);
+            const unsigned mg = (st[u][kk].w == sh) ? st[u][kk].y : st[u][kk].x;
+            sum = sum + __uint_as_float(FQ_ANDOR(st[u][kk].z << sh, 0x80000000u, mg));
+          }
+          if (i < VPT - 2 || w < a.var_words) ffsum[w] = sum + 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // bounds the records in flight (live registers)
+      }
+      __syncthreads();
+    }
+
+    if (vec_out) {
+      fq_u2 *o8 = (fq_u2 *)(a.bits + (size_t)frame * a.n);
+      const unsigned *us = (const unsigned *)ffsum;
+      for (int i = tid; i < (a.n >> 3); i += B) {
+        const fq_u4 w = pos8[i];
+        fq_u2 b;
+        b.x = (us[w.x & 0xffffu] >> 31) | ((us[w.x >> 16] >> 31) << 8) | ((us[w.y & 0xffffu] >> 31) << 16) | ((us[w.y >> 16] >> 31) << 24);
+        b.y = (us[w.z & 0xffffu] >> 31) | ((us[w.z >> 16] >> 31) << 8) | ((us[w.w & 0xffffu] >> 31) << 16) | ((us[w.w >> 16] >> 31) << 24);
+        __builtin_nontemporal_store(b, o8 + i);
+      }
+    } else if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = ffsum[a.pos[i]] < 0.0f;
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = ffsum[a.pos[i]];
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (has[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    if (tid == 0) *frame_slot = next_frame;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// the shapes the register-cached kernel is built for: {checks per thread, slot pairs, variables
+// per thread, edges per variable}
+#define FF_REG_SHAPES(X) \
+  X(4, 16, 32, 3, 512, 2) X(2, 16, 16, 3, 1024, 4)
+
 namespace {
 
 typedef void (*FfKern)(FfArgs);
@@ -229,15 +501,24 @@ FfKern ff_pick(int cpt) {
   return nullptr;
 }
 
+
+FfKern ff_reg_lookup(int cpt, int r2, int vpt, int cm, int block) {
+#define FF_X(C, R, V, M, LB, MW) if (cpt == C && r2 == R && vpt == V && cm == M && block == LB) return fused_ms_reg_kernel<C, R, V, M, LB, MW>;
+  FF_REG_SHAPES(FF_X)
+#undef FF_X
+  return nullptr;
+}
+
 template <typename T>
 struct FusedFloatEngine : Engine {
   ldpc_opts opts{};
   int n = 0, m = 0, rmax = 0, cmax = 0, RM = 0, NW = 1;
   int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
   size_t lds = 0;
-  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter;
+  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter, d_vtabT, d_maskT;
   LdsSchedule sched;
   FfKern kern = nullptr;
+  bool use_reg = false;
 
   static size_t lds_bytes(int words, int var_words, int m, int nw) {
     const int sgw = nw == 1 ? 2 : 4;
@@ -260,19 +541,93 @@ struct FusedFloatEngine : Engine {
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     RM = std::max(2, 2 * ((rmax + 1) / 2));
     NW = (RM + 31) / 32;
-    // workgroup shape: up to 16 wavefronts, every wavefront with the same number of checks
     const int need = (m + 63) / 64;
+    int optimise = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
+    int env_w = 0, env_reg = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_WAVES")) env_w = atoi(e);
+    if (const char *e = getenv("LDPC_HIP_FUSED_REG")) env_reg = atoi(e);
+    std::vector<int> row_of(c.E());
+    for (int j = 0; j < m; j++)
+      for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
+    int rc;
+
+    // First choice: the register-cached binary32 kernel, if one is built for this shape.  Try
+    // the workgroup shapes in order of SIMD balance (wavefronts go to the 4 SIMDs in turn; the
+    // busiest sets the pace; a wavefront of the last, partial round runs the shorter stream).
+    use_reg = false;
+    if (env_reg && sizeof(T) == 4 && NW == 1 && m <= 2047 && cmax >= 1) {
+      std::vector<std::pair<double, int>> cand;
+      for (int W = 1; W <= 16; W++) {
+        if (env_w && W != env_w) continue;
+        const int r = (need + W - 1) / W;
+        if (r > 4) continue;
+        const int full = need - (r - 1) * W;
+        int load[4] = {0, 0, 0, 0};
+        for (int w = 0; w < W; w++) load[w & 3] += w < full ? r : r - 1;
+        const int worst = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+        cand.push_back({-((double)need / (4.0 * worst) + 0.002 * W), W});
+      }
+      std::sort(cand.begin(), cand.end());
+      for (auto &cw : cand) {
+        const int W = cw.second, B = W * 64;
+        LdsSchedule sc;
+        if (ldpc_build_lds_schedule(c, B, RM, FF_NDUMMY, optimise != 0, sc)) continue;
+        int vpt = (sc.var_words + B - 1) / B;
+        if ((cmax & 1) && (vpt & 1)) vpt++;
+        FfKern k = ff_reg_lookup(sc.rounds, RM / 2, vpt, cmax, B);
+        if (!k) continue;
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void *)k));
+        if ((size_t)sc.words * 4 + fa.sharedSizeBytes > 65535) continue;   // 16-bit absolute slot addresses
+        const size_t need_lds = (size_t)sc.words * 4 + (size_t)(m + 1) * 16 + (size_t)sc.var_words * 4 + 16;
+        if (need_lds + fa.sharedSizeBytes > 160 * 1024) continue;
+        // edges of the variables each thread rebuilds: (check << 5) | shift of the sign bit
+        std::vector<int> inv(sc.var_words, -1);
+        for (int v = 0; v < n; v++) inv[sc.pos[v]] = v;
+        std::vector<int> slot_of_edge(c.E(), -1);
+        for (int j = 0; j < m; j++)
+          for (int kk = 0; kk < RM; kk++) {
+            const int w = sc.colT[((size_t)(j / B) * RM + kk) * B + j % B];
+            if (w >= sc.dummy_base) continue;
+            for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++)
+              if (sc.pos[c.col_idx[e]] == w) slot_of_edge[e] = kk;
+          }
+        std::vector<uint16_t> vt((size_t)vpt * cmax * B, (uint16_t)(m << 5));
+        bool lost = false;
+        for (int t = 0; t < B; t++)
+          for (int i = 0; i < vpt; i++) {
+            const int w = t + B * i;
+            if (w >= sc.var_words || inv[w] < 0) continue;
+            const int v = inv[w];
+            for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++) {
+              const int e = c.edge_of[c.col_ptr[v] + kk];
+              if (slot_of_edge[e] < 0) lost = true;
+              vt[((size_t)i * cmax + kk) * B + t] = (uint16_t)((row_of[e] << 5) | (32 - RM + slot_of_edge[e]));
+            }
+          }
+        if (lost) continue;
+        sched = sc;
+        kern = k; use_reg = true;
+        block = B; rounds = sc.rounds;
+        lds = need_lds;
+        if ((rc = d_vtabT.ensure(vt.size() * 2))) return rc;
+        if ((rc = d_maskT.ensure(sc.maskT.size() * 4))) return rc;
+        HIPCHK(hipMemcpy(d_vtabT.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_maskT.p, sc.maskT.data(), sc.maskT.size() * 4, hipMemcpyHostToDevice));
+        wg_per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)std::max(1, 16 / W));
+        if (wg_per_cu < 1) wg_per_cu = 1;
+        break;
+      }
+    }
+    if (!use_reg) {
+    // generic kernel: up to 16 wavefronts, every wavefront with the same number of checks
     int W = std::min(16, need);
     rounds = (need + W - 1) / W;
     if (rounds > 8) { ldpc_set_error("fused min-sum: too many checks"); return LDPC_ERR_UNSUPPORTED; }
     W = (need + rounds - 1) / rounds;
-    if (const char *e = getenv("LDPC_HIP_FUSED_WAVES")) {
-      const int w = atoi(e);
-      if (w >= 1 && w <= 16 && (need + w - 1) / w <= 8) { W = w; rounds = (need + W - 1) / W; }
-    }
+    if (env_w >= 1 && env_w <= 16 && (need + env_w - 1) / env_w <= 8) { W = env_w; rounds = (need + W - 1) / W; }
     block = W * 64;
-    int optimise = 1;
-    if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
     if (ldpc_build_lds_schedule(c, block, RM, FF_NDUMMY, optimise != 0, sched)) {
       ldpc_set_error("LDS schedule: code too large");
       return LDPC_ERR_UNSUPPORTED;
@@ -285,10 +640,12 @@ struct FusedFloatEngine : Engine {
     }
     wg_per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)std::max(1, 16 / W));
     if (wg_per_cu < 1) wg_per_cu = 1;
+    }
     if (const char *e = getenv("LDPC_HIP_FUSED_WG_PER_CU")) {
       const int g = atoi(e);
       if (g >= 1 && (size_t)g * (lds + 512) <= 160 * 1024) wg_per_cu = g;
     }
+    if (!use_reg)
     kern = NW == 1 ? ff_pick<T, 1>(rounds) : ff_pick<T, 2>(rounds);
     if (!kern) { ldpc_set_error("no fused min-sum kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
 
@@ -305,9 +662,6 @@ struct FusedFloatEngine : Engine {
           if (sched.pos[c.col_idx[e]] == w) slot_of_edge[e] = k;
       }
     }
-    std::vector<int> row_of(c.E());
-    for (int j = 0; j < m; j++)
-      for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
     std::vector<uint32_t> vtab((size_t)std::max(1, cmax) * sched.var_words, (uint32_t)m << 8);
     for (int v = 0; v < n; v++)
       for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++) {
@@ -315,7 +669,6 @@ struct FusedFloatEngine : Engine {
         if (slot_of_edge[e] < 0) { ldpc_set_error("fused min-sum: schedule lost an edge"); return LDPC_ERR_FORMAT; }
         vtab[(size_t)kk * sched.var_words + sched.pos[v]] = ((uint32_t)row_of[e] << 8) | (uint32_t)slot_of_edge[e];
       }
-    int rc;
     if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
     if ((rc = d_realT.ensure(realT.size() * 4))) return rc;
     if ((rc = d_vtab.ensure(vtab.size() * 4))) return rc;
@@ -357,6 +710,8 @@ struct FusedFloatEngine : Engine {
     a.llr = llr; a.dt = dt; a.synd = sy;
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
     a.counter = d_counter.as<int>();
+    a.vtabT = d_vtabT.as<uint16_t>();
+    a.maskT = d_maskT.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
     prof_begin(K_FUSED, st);
