@@ -519,6 +519,7 @@ struct FusedFloatEngine : Engine {
   LdsSchedule sched;
   FfKern kern = nullptr;
   bool use_reg = false;
+  long vconf_before = 0, vconf_after = 0;   // extra LDS cycles of the variable pass per iteration (model)
 
   static size_t lds_bytes(int words, int var_words, int m, int nw) {
     const int sgw = nw == 1 ? 2 : 4;
@@ -582,6 +583,7 @@ struct FusedFloatEngine : Engine {
         if ((size_t)sc.words * 4 + fa.sharedSizeBytes > 65535) continue;   // 16-bit absolute slot addresses
         const size_t need_lds = (size_t)sc.words * 4 + (size_t)(m + 1) * 16 + (size_t)sc.var_words * 4 + 16;
         if (need_lds + fa.sharedSizeBytes > 160 * 1024) continue;
+        if (optimise) ldpc_place_variable_pass(c, sc, &vconf_before, &vconf_after);
         // edges of the variables each thread rebuilds: (check << 5) | shift of the sign bit
         std::vector<int> inv(sc.var_words, -1);
         for (int v = 0; v < n; v++) inv[sc.pos[v]] = v;
@@ -617,6 +619,9 @@ struct FusedFloatEngine : Engine {
         HIPCHK(hipMemcpy(d_maskT.p, sc.maskT.data(), sc.maskT.size() * 4, hipMemcpyHostToDevice));
         wg_per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)std::max(1, 16 / W));
         if (wg_per_cu < 1) wg_per_cu = 1;
+        if (getenv("LDPC_HIP_DEBUG"))
+          fprintf(stderr, "fused float: %d waves, %d checks/thread, %d variables/thread, variable-pass extra LDS cycles %ld -> %ld of %d group reads\n",
+                  W, sc.rounds, vpt, vconf_before, vconf_after, ((sc.var_words + 63) / 64) * 4 * cmax);
         break;
       }
     }

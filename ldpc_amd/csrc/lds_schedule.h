@@ -19,3 +19,8 @@ struct LdsSchedule {
 // ndummy: dummy words (multiple of 32).  optimise = false keeps the natural layout.
 int ldpc_build_lds_schedule(const ldpc_code &c, int block, int RM, int ndummy, bool optimise,
                             LdsSchedule &out);
+
+// Re-ranks the variables within their LDS banks (vpass_place.cpp) so that the record reads of
+// the fused float kernel's variable pass meet few bank conflicts; rewrites sc.pos / sc.colT.
+// *before / *after: modelled extra LDS cycles per iteration.
+void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after);

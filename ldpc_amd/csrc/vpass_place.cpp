@@ -1,0 +1,105 @@
+// vpass_place.cpp -- host-side placement of variables for the variable pass of the fused
+// floating-point min-sum kernel (fused_float.hip): see ldpc_place_variable_pass().
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "lds_schedule.h"
+
+// Variable pass placement.  The check pass fixed each variable's LDS bank (word mod 32); its
+// rank within the bank is still free, and it decides which 16 variables share a lane group of
+// a ds_read_b128 in the variable pass (thread tid rebuilds words tid + B*i: lane = word mod 64,
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32).  A group is served in one
+// LDS cycle when its 16 records sit in 16 different bank quads (record index mod 16); random
+// ranks give ~3.  Local search over swaps of two variables of one bank: cost = sum over
+// groups and edges of the busiest quad.  Returns the extra LDS cycles left (and before).
+void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after) {
+  std::vector<int> row_of(c.E());
+  for (int j = 0; j < c.m; j++)
+    for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
+  const int W = sc.var_words, CM = std::max(1, c.cmax), NT = ((W + 63) / 64) * 4;
+  std::vector<int> occ(W, -1);
+  for (int v = 0; v < c.n; v++) occ[sc.pos[v]] = v;
+  auto tuple_of = [](int w) {
+    const int l = w & 63, b = l & 31;
+    const bool a = b <= 3 || (b >= 12 && b <= 15) || (b >= 20 && b <= 27);
+    return (w >> 6) * 4 + (l >> 5) * 2 + (a ? 0 : 1);
+  };
+  std::vector<std::vector<int>> members(NT);
+  for (int w = 0; w < W; w++) members[tuple_of(w)].push_back(w);
+  std::vector<int8_t> quad((size_t)c.n * CM, -1);
+  for (int v = 0; v < c.n; v++)
+    for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++)
+      quad[(size_t)v * CM + kk] = (int8_t)(row_of[c.edge_of[c.col_ptr[v] + kk]] & 15);
+  auto cost = [&](int t) {
+    int total = 0;
+    for (int kk = 0; kk < CM; kk++) {
+      int cnt[16] = {0}, mx = 0;
+      for (int w : members[t]) {
+        const int v = occ[w];
+        if (v < 0) continue;
+        const int q = quad[(size_t)v * CM + kk];
+        if (q >= 0) mx = std::max(mx, ++cnt[q]);
+      }
+      total += mx > 0 ? mx - 1 : 0;
+    }
+    return total;
+  };
+  long sum = 0;
+  for (int t = 0; t < NT; t++) sum += cost(t);
+  *before = sum;
+  // simulated annealing on swaps of two variables of one bank.  Energy per (group, edge):
+  // 16 * (busiest quad - 1) + number of surplus entries (the second term guides the search
+  // where the first is flat).  Counts are kept per (group, edge, quad).
+  std::vector<uint8_t> cnt((size_t)NT * CM * 16, 0);
+  auto energy_of = [&](int t, int kk) {
+    const uint8_t *q = &cnt[((size_t)t * CM + kk) * 16];
+    int mx = 0, surplus = 0;
+    for (int i = 0; i < 16; i++) { mx = std::max<int>(mx, q[i]); surplus += q[i] > 1 ? q[i] - 1 : 0; }
+    return 16 * (mx > 0 ? mx - 1 : 0) + surplus;
+  };
+  auto add = [&](int t, int v, int d) {
+    if (v < 0) return;
+    for (int kk = 0; kk < CM; kk++) {
+      const int q = quad[(size_t)v * CM + kk];
+      if (q >= 0) cnt[((size_t)t * CM + kk) * 16 + q] = (uint8_t)(cnt[((size_t)t * CM + kk) * 16 + q] + d);
+    }
+  };
+  std::vector<int> tw(W);
+  for (int w = 0; w < W; w++) { tw[w] = tuple_of(w); add(tw[w], occ[w], +1); }
+  auto energy_t = [&](int t) { int e = 0; for (int kk = 0; kk < CM; kk++) e += energy_of(t, kk); return e; };
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 32); };
+  const int ranks = W / 32;
+  const long moves = std::min<long>(150L * W, 8000000L);
+  // acceptance of an uphill move of size d: d <= budget, a threshold that falls linearly to 0
+  for (long it = 0; it < moves && ranks > 1; it++) {
+    const int w = (int)(rnd() % (uint32_t)W);
+    const int w2 = (w & 31) + 32 * (int)(rnd() % (uint32_t)ranks);
+    const int t = tw[w], t2 = tw[w2];
+    if (t == t2 || (occ[w] < 0 && occ[w2] < 0)) continue;
+    const int e0 = energy_t(t) + energy_t(t2);
+    add(t, occ[w], -1); add(t2, occ[w2], -1);
+    add(t, occ[w2], +1); add(t2, occ[w], +1);
+    const int e1 = energy_t(t) + energy_t(t2);
+    const int budget = (int)(12 * (moves - it) / moves);
+    if (e1 - e0 <= budget - (int)(rnd() % (uint32_t)(budget + 1))) {
+      std::swap(occ[w], occ[w2]);
+    } else {
+      add(t, occ[w2], -1); add(t2, occ[w], -1);
+      add(t, occ[w], +1); add(t2, occ[w2], +1);
+    }
+  }
+  sum = 0;
+  for (int t = 0; t < NT; t++) sum += cost(t);
+  *after = sum;
+  // apply: variables move within their bank, so the check pass's schedule stays conflict free
+  std::vector<uint16_t> newword(sc.words);
+  for (int w = 0; w < sc.words; w++) newword[w] = (uint16_t)w;
+  for (int w = 0; w < W; w++)
+    if (occ[w] >= 0) newword[sc.pos[occ[w]]] = (uint16_t)w;
+  for (auto &x : sc.colT) x = newword[x];
+  for (int w = 0; w < W; w++)
+    if (occ[w] >= 0) sc.pos[occ[w]] = (uint16_t)w;
+}
+
