@@ -482,7 +482,10 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
 // the shapes the register-cached kernel is built for: {checks per thread, slot pairs, variables
 // per thread, edges per variable}
 #define FF_REG_SHAPES(X) \
-  X(4, 16, 32, 3, 512, 2) X(2, 16, 16, 3, 1024, 4)
+  X(2, 16, 16, 3, 1024, 4) /* peg_16000_3_0.9 */ \
+  X(2, 9, 10, 3, 512, 4)   /* 4095.737.3: two workgroups per CU */ \
+  X(1, 7, 6, 3, 256, 4)    /* 1057.244.3: four */ \
+  X(1, 3, 2, 3, 128, 4)    /* 204.33.484: eight */
 
 namespace {
 
