@@ -189,11 +189,11 @@ def measured_traffic(kernel, args, F):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), scaled by
     frames per launch; None when no pass was taken for this kernel / workload."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if args.code != CODE or args.alg != "q88" or args.iters != 10 or not os.path.exists(path):
+    if args.code != CODE or args.iters != 10 or not os.path.exists(path):
         return None
     with open(path) as f:
-        t = json.load(f)
-    if t.get("kernel") != kernel:
+        t = json.load(f).get(args.alg)
+    if not t or t.get("kernel") != kernel:
         return None
     return int(round(t["hbm_bytes_per_frame"] * F))
 

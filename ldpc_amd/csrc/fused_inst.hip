@@ -12,7 +12,8 @@ namespace ldpc {
 
 template <int CPT, int R2, int SH>
 static FusedKern fq_one() {
-  if constexpr (fq_reg_shape_ok(CPT, R2)) return fused_q88_reg_kernel<CPT, R2, SH, 1024, 4>;
+  if constexpr (fq_reg_max_block(CPT, R2) == 1024) return fused_q88_reg_kernel<CPT, R2, SH, 1024, 4>;
+  else if constexpr (fq_reg_max_block(CPT, R2) == 768) return fused_q88_reg_kernel<CPT, R2, SH, 768, 3>;
   else return nullptr;
 }
 

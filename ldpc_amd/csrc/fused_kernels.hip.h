@@ -77,6 +77,13 @@ inline int fq_round_r2(int r2) {
 constexpr bool fq_reg_shape_ok(int cpt, int r2) {
   return cpt == 1 ? r2 <= 32 : cpt == 2 ? r2 <= 16 : cpt == 3 ? r2 <= 9 : false;
 }
+// Largest workgroup a shape's kernel is built for: 1024 threads (16 waves x 128 VGPRs) for the
+// shapes above; three checks per thread of up to 22 slot pairs get a 12-wave build (168 VGPRs:
+// the few values the compiler still spills are touched outside the iteration loop or a dozen
+// times per iteration, against ~2000 VALU instructions).  0: no kernel.
+constexpr int fq_reg_max_block(int cpt, int r2) {
+  return fq_reg_shape_ok(cpt, r2) ? 1024 : (cpt == 3 && r2 <= 22) ? 768 : 0;
+}
 FusedKern fused_reg_lookup_part0(int cpt, int r2, int sh);
 FusedKern fused_reg_lookup_part1(int cpt, int r2, int sh);
 FusedKern fused_reg_lookup_part2(int cpt, int r2, int sh);

@@ -615,7 +615,7 @@ struct FusedQ88Engine : Engine {
     if (c.rmax > 64) return false;
     const int need = (c.m + 63) / 64, r2 = fq_round_r2((c.rmax + 1) / 2);
     for (int W = 1; W <= 16; W++)
-      if (fq_reg_shape_ok((need + W - 1) / W, r2)) return true;
+      if (W * 64 <= fq_reg_max_block((need + W - 1) / W, r2)) return true;
     return false;
   }
 
@@ -660,7 +660,7 @@ struct FusedQ88Engine : Engine {
           if (env_w && W != env_w) continue;
           if (env_g && G != env_g) continue;
           const int r = (need + W - 1) / W;
-          if (!fq_reg_shape_ok(r, r2)) continue;
+          if (W * 64 > fq_reg_max_block(r, r2)) continue;
           // wavefront w owns r groups of 64 checks if w < full, else r - 1 (and runs the shorter
           // instruction stream); wavefronts go to the 4 SIMDs in turn, the busiest SIMD sets the pace
           const int full = need - (r - 1) * W;
