@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
   typedef typename MT<T>::vec vec;
   typedef typename MT<T>::acc acc;
   constexpr int V = MT<T>::V;
-  static_assert(ALG == ALG_MS || ALG == ALG_MSQ, "register variant is min-sum only");
+  static_assert(ALG == ALG_MS || ALG == ALG_MSQ || ALG == ALG_SPA, "register variant: min-sum and float sum-product");
   const int lane = threadIdx.x & 63;
   const int w = wave_id_uniform();
   const int nw = (int)((gridDim.x * blockDim.x) >> 6);
@@ -522,6 +522,44 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
         par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
       }
     failacc |= par;
+    if constexpr (ALG == ALG_SPA) {
+      // test_code_B_float.c:159-178 with log tanh(|v2c|/2) of every row evaluated once and kept
+      // (in the row's own registers; its sign goes to a bit mask): the same values, sums and
+      // differences as the two-sweep kernels, half the transcendentals, one read of the rows
+      static_assert(RB * V <= 64, "sign mask");
+      unsigned long long negm = 0;
+      acc lp[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) lp[v] = 0;
+#pragma unroll
+      for (int k = 0; k < RB; k++)
+        if (k < dc) {
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const acc xv = (acc)x[k][v];
+            const bool neg = xv < 0;
+            const acc l = spa_logtanh2(neg ? -xv : xv);
+            lp[v] = lp[v] + l;
+            x[k][v] = (T)l;
+            negm |= (unsigned long long)(neg ? 1u : 0u) << (k * V + v);
+            sg ^= (neg ? 1u : 0u) << v;
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < RB; k++)
+        if (k < dc) {
+          vec o;
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const acc tout = spa_atanh2exp(lp[v] - (acc)x[k][v]);
+            const bool neg = ((negm >> (k * V + v)) & 1ull) != 0;
+            const bool flip = (((sg >> v) & 1u) != 0) != neg;
+            o[v] = (T)(flip ? -tout : tout);
+          }
+          rows[(size_t)k * 64] = o;
+        }
+      continue;
+    }
     CnStateMin<acc> st[V];
     const acc big = ALG == ALG_MSQ ? (acc)Q88_CAP200 : (acc)200;
 #pragma unroll

@@ -234,11 +234,14 @@ struct BinaryEngine : Engine {
     // measured on PEG-16000 (tools/bench_codes.py): the single-read kernel wins for min-sum
     // (+11 % over the reload kernel), the reload kernel for the float sum-product (+48 % over
     // the LDS-staged one), the DMA-staged one for the table sum-product
+    // (float sum-product with row weights <= 16, e.g. the DVB-S2 codes: register-resident kernel)
     if (cn_variant == 0)
-      cn_variant = ((ALG == ALG_MS || ALG == ALG_MSQ) && rmax <= 64) ? 5 : (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 : 2;
+      cn_variant = ((ALG == ALG_MS || ALG == ALG_MSQ) && rmax <= 64) ? 5 : (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 :
+                   (ALG == ALG_SPA && rmax <= 16) ? 3 : 2;
     const size_t lds_need = (size_t)rmax * 1024;
     if ((cn_variant == 1 || cn_variant == 4) && lds_need > 160 * 1024) cn_variant = 2;
-    if (cn_variant == 3 && (rmax > 32 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 1;
+    if (cn_variant == 3 && ALG == ALG_SPA && rmax > 16) cn_variant = 2;
+    if (cn_variant == 3 && (rmax > 32 || !(ALG == ALG_MS || ALG == ALG_MSQ || ALG == ALG_SPA))) cn_variant = 1;
     if (cn_variant == 5 && (rmax > 64 || !(ALG == ALG_MS || ALG == ALG_MSQ))) cn_variant = 2;
     if (cn_variant == 1 && lds_need > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void *)cn_kernel<T, ALG, false>,
@@ -314,14 +317,14 @@ struct BinaryEngine : Engine {
     const long waves = (long)wps * nslab;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (cn_variant == 3) {
-      if constexpr (ALG == ALG_MS || ALG == ALG_MSQ) {
+      if constexpr (ALG == ALG_MS || ALG == ALG_MSQ || ALG == ALG_SPA) {
         if (rmax <= 8)
           hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 8>), grid, block, 0, st, g, nslab, msg.as<vec>(),
                              hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
         else if (rmax <= 16)
           hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 16>), grid, block, 0, st, g, nslab, msg.as<vec>(),
                              hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
-        else
+        else if constexpr (ALG != ALG_SPA)
           hipLaunchKernelGGL((cn_reg_kernel<T, ALG, 32>), grid, block, 0, st, g, nslab, msg.as<vec>(),
                              hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
       }

@@ -279,3 +279,30 @@ def test_fused_float_minsum_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it
         # the two-pass engine (cn_variant != 0) must agree with it
         two = two or hip.Decoder(code, alg, max_frames=16, cn_variant=2)
         check_exact(two.decode(inp, su, it), ref, f"two-pass float {prec} {kind} random {n}x{m} dv={dv}")
+
+
+@pytest.mark.parametrize("name,F,p,it", [("204.33.484.txt", 200, 0.06, 15), ("Frolov_1024_0.5.txt", 40, 0.07, 20),
+                                         ("dvb_H_0.5.txt", 6, 0.08, 12)])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_spa_register_kernel_equals_two_sweep_kernels(hip, oracle, tmp_path, name, F, p, it, prec):
+    """The register-resident sum-product check kernel (default for row weights <= 16, e.g. the
+    DVB-S2 code) evaluates log tanh once per row and keeps it; the two-sweep kernels evaluate
+    it twice.  Same device libm, same values, same order of sums: every output must be
+    identical, posterior LLRs included, whichever kernel ran."""
+    path = code_path(name)
+    if name.startswith("dvb"):     # (the reference-style loader of the oracle needs the padded dialect)
+        path = str(tmp_path / "padded.alist")
+        hip.alist.normalise_alist(code_path(name), path, padded=True)
+    oc = oracle.load(path)
+    x, s, llr = make_frames(oracle, oc, F, p, 31, "awgn", sigma=0.9)
+    inp = llr.astype(np.float32 if prec == "f32" else np.float64)
+    alg = hip.ALG.SPA_F32 if prec == "f32" else hip.ALG.SPA_F64
+    code = hip.Code.from_alist(code_path(name))
+    want = ("bits", "iters", "synd", "status", "llr")
+    outs = []
+    for variant in (0, 3, 2, 1):
+        dec = hip.Decoder(code, alg, max_frames=256, want_llr=True, cn_variant=variant)
+        outs.append(dec.decode(inp, s.astype(np.uint8), it, want=want))
+    for o in outs[1:]:
+        for k in want:
+            assert np.array_equal(o[k], outs[0][k], equal_nan=True) if k == "llr" else np.array_equal(o[k], outs[0][k]), k
