@@ -62,6 +62,9 @@ struct FfArgs {
   const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
 };
 
+#ifndef FF_ONEHOT
+#define FF_ONEHOT 0   /* 1: old-minimum slot by a rotating one-hot mask instead of a compare per slot */
+#endif
 #define FF_NDUMMY 64
 #define FF_CAP 200          /* min_msg starts at 200 (test_code_min_sum_B.c:169) */
 
@@ -368,9 +371,13 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
               // parity of the hard decisions (sums are stored as sum + 0.0: sign bit <=> sum < 0)
               if ((j & 1) == 0) pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
               // old magnitude of this slot: min2 in the slot of min1 (its one-hot mask rotates with the signs)
+#if FF_ONEHOT
               const unsigned sel = (unsigned)((int)oarot[r] >> 31);
               oarot[r] = fq_shl1(oarot[r]);
               const float mo = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(om2[r]), __float_as_uint(om1[r]), 0xCA));
+#else
+              const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
+#endif
               const float q = __int_as_float(S[r][j]) - __uint_as_float(FQ_ANDOR(orot[r], 0x80000000u, __float_as_uint(mo)));
               orot[r] = fq_shl1(orot[r]);
               sg[r] = __builtin_amdgcn_alignbit(sg[r], __float_as_uint(q), 31);
@@ -385,7 +392,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
           // up after the last chunk with every sum it read still live
 #pragma unroll
           for (int r = 0; r < NA; r++)
+#if FF_ONEHOT
             asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]), "+v"(orot[r]), "+v"(oarot[r]));
+#else
+            asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]), "+v"(orot[r]));
+#endif
           __builtin_amdgcn_sched_barrier(0);   // keeps a chunk's work in the chunk (live registers)
         }
 #pragma unroll

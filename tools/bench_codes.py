@@ -37,7 +37,7 @@ def main():
         n, m = code.n, code.m
         L = math.log((1 - p) / p)
         for alg, dt, tdt in algs:
-            budget = 2.0e9 if alg.startswith("MINSUM") else 1.2e9        # bytes of edge messages resident
+            budget = float(os.environ.get("BENCH_CODES_BUDGET", 2.0e9 if alg.startswith("MINSUM") else 1.2e9))        # bytes of edge messages resident
             F = int(min(65536, max(256, budget // (code.E * 8))))
             F -= F % 64
             gen = torch.Generator(device=dev)
