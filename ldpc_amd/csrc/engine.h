@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -22,9 +23,17 @@ void ldpc_set_error(const std::string &s);
     }                                                                             \
   } while (0)
 
+// LDPC_HIP_SYNC=1 (debugging): wait for every kernel right after its launch, so that a fault is
+// reported against the kernel that caused it instead of at the next copy
+inline bool ldpc_sync_launches() {
+  static const bool on = [] { const char *e = getenv("LDPC_HIP_SYNC"); return e && atoi(e) != 0; }();
+  return on;
+}
+
 #define LAUNCHCHK(name)                                                           \
   do {                                                                            \
     hipError_t e_ = hipGetLastError();                                            \
+    if (e_ == hipSuccess && ldpc_sync_launches()) e_ = hipDeviceSynchronize();    \
     if (e_ != hipSuccess) {                                                       \
       ldpc_set_error(std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
       return LDPC_ERR_HIP;                                                        \

@@ -697,8 +697,18 @@ struct FusedFloatEngine : Engine {
     HIPCHK(hipMemcpy(d_realT.p, realT.data(), realT.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_vtab.p, vtab.data(), vtab.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pos.p, sched.pos.data(), sched.pos.size() * 2, hipMemcpyHostToDevice));
-    if (lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      // (the attribute belongs to the kernel, not to this decoder: another decoder of a smaller
+      // code that uses the same instantiation must not lower it, so it is always the maximum)
+      hipFuncAttributes fa;
+      HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)fa.sharedSizeBytes));
+      if (lds + fa.sharedSizeBytes > 160 * 1024) {
+        ldpc_set_error("fused min-sum: frame does not fit in LDS");
+        return LDPC_ERR_UNSUPPORTED;
+      }
+    }
     return LDPC_OK;
   }
 

@@ -492,7 +492,13 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           for (int w = 0; w < NW; w++) tot ^= (unsigned)__popc(sg[r][w]);
           nm1[r] = fq_finish_minf(__uint_as_float(k1[r] & ~KM));
           nm2[r] = fq_finish_minf(__uint_as_float(k2m[r] & ~KM));
-          narg[r] = k1[r] & KM;
+          // A thread with no check at all (beyond m in a wavefront that has checks) sees only pad
+          // slots, whose dummy words carry this phase's racing adds: 2^24 + delta is not on the
+          // 5-zero-bit grid the key packing relies on, so the slot bits can come out >= RM.  Its
+          // messages are all "cap" and nothing it adds matters, but the index below must stay
+          // inside colT (an out-of-bounds read, up to 9 KB past the table, faulted once the
+          // neighbouring pages were unmapped).
+          narg[r] = min(k1[r] & KM, (unsigned)(RM - 1));
           // where slot narg's variable lives (needed by phase B's fix-up; the load hides under the barrier)
           {
             // opaque pointer: keeps the compiler from relating this load to the index registers

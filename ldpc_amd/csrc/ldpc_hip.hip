@@ -738,8 +738,15 @@ struct FusedQ88Engine : Engine {
     }
     if (!kern) { ldpc_set_error("no fused kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
     if (lds > 160 * 1024) { ldpc_set_error("fused decoder: frame does not fit in LDS"); return LDPC_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      // (the attribute belongs to the kernel, not to this decoder: a later decoder of a smaller
+      // code with the same instantiation must not lower it, so it is always the maximum)
+      hipFuncAttributes fa;
+      HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)fa.sharedSizeBytes));
+      if (lds + fa.sharedSizeBytes > 160 * 1024) { ldpc_set_error("fused decoder: frame does not fit in LDS"); return LDPC_ERR_UNSUPPORTED; }
+    }
     if ((rc = d_counter.ensure(256))) return rc;
     return LDPC_OK;
   }
