@@ -180,6 +180,15 @@ int ldpc_decoder_last_iterations(const ldpc_decoder *d);
  * Host only; needs no GPU. */
 int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, int64_t *stats);
 
+/* Diagnostics of the variable-pass placement of the fused floating-point min-sum
+ * decoder (no counterpart in the reference): builds the LDS schedule for workgroups
+ * of `block` threads, re-ranks the variables within their banks and returns
+ * stats[4] = {modelled extra LDS cycles of the variable pass per iteration before,
+ * after, 16-lane group reads per iteration, self-check errors of the rewritten
+ * schedule (must be 0: every variable still in its bank, on its own word, and every
+ * check still visiting exactly its variables)}.  Host only; needs no GPU. */
+int ldpc_code_vpass_place_stats(const ldpc_code *c, int block, int64_t *stats);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only
  * instrumentation is clock() around the trial loop, test_code_B.c:334,354-356).
  * With profiling enabled every launch of the decoding kernels is bracketed by a

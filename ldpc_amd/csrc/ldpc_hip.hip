@@ -905,6 +905,39 @@ extern "C" int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int o
   return LDPC_OK;
 }
 
+extern "C" int ldpc_code_vpass_place_stats(const ldpc_code *c, int block, int64_t *stats) {
+  if (!c || !stats || block <= 0 || block % 64 || c->rmax > 64 || c->q != 2) return LDPC_ERR_ARG;
+  const int RM = std::max(2, 2 * ((c->rmax + 1) / 2));
+  LdsSchedule s0, s;
+  if (ldpc_build_lds_schedule(*c, block, RM, 64, true, s0)) return LDPC_ERR_UNSUPPORTED;
+  s = s0;
+  long before = 0, after = 0;
+  ldpc_place_variable_pass(*c, s, &before, &after);
+  stats[0] = before; stats[1] = after; stats[2] = (int64_t)((s.var_words + 63) / 64) * 4 * c->cmax;
+  int64_t bad = 0;
+  std::vector<int> inv(s.words, -1);
+  for (int v = 0; v < c->n; v++) {
+    if (s.pos[v] >= s.var_words || inv[s.pos[v]] >= 0) bad++;
+    else inv[s.pos[v]] = v;
+    if ((s.pos[v] & 31) != (s0.pos[v] & 31)) bad++;          // left its bank
+  }
+  for (int j = 0; j < c->m && !bad; j++) {
+    std::vector<int> want(c->col_idx.begin() + c->row_ptr[j], c->col_idx.begin() + c->row_ptr[j + 1]), got;
+    const int r = j / block, t = j % block;
+    for (int k = 0; k < RM; k++) {
+      const size_t at = ((size_t)r * RM + k) * block + t;
+      if ((s.colT[at] < s.dummy_base) != (s0.colT[at] < s0.dummy_base)) bad++;
+      if (s.colT[at] < s.dummy_base) got.push_back(inv[s.colT[at]]);
+      else if (s.colT[at] != s0.colT[at]) bad++;              // pad slots keep their dummy word
+    }
+    std::sort(want.begin(), want.end());
+    std::sort(got.begin(), got.end());
+    if (want != got) bad++;
+  }
+  stats[3] = bad;
+  return LDPC_OK;
+}
+
 extern "C" int ldpc_decoder_profile(ldpc_decoder *d, int enable) {
   if (!d) return LDPC_ERR_ARG;
   d->eng->profiling = enable != 0;

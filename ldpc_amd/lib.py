@@ -89,6 +89,7 @@ def load_library():
     L.ldpc_decode_batch_device.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ldpc_decode_trace_q88.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, vp, cp, ip]
     L.ldpc_code_lds_schedule_stats.argtypes = [vp, ip, ip, vp]
+    L.ldpc_code_vpass_place_stats.argtypes = [vp, ip, vp]
     L.ldpc_decoder_profile.argtypes = [vp, ip]
     L.ldpc_decoder_profile_read.argtypes = [vp, vp, vp]
     L.ldpc_mc_create.argtypes = [vp, vp, ip, C.POINTER(vp)]
@@ -188,6 +189,12 @@ class Code:
         st = np.zeros(5, np.int64)
         check(load_library().ldpc_code_lds_schedule_stats(self._h, int(block), int(optimise), _ptr(st)))
         return dict(conflicts=int(st[0]), accesses=int(st[1]), words=int(st[2]), slots=int(st[3]), errors=int(st[4]))
+
+    def vpass_place_stats(self, block):
+        """Variable-pass placement of the fused floating-point min-sum decoder (host only)."""
+        st = np.zeros(4, np.int64)
+        check(load_library().ldpc_code_vpass_place_stats(self._h, int(block), _ptr(st)))
+        return dict(before=int(st[0]), after=int(st[1]), reads=int(st[2]), errors=int(st[3]))
 
     def close(self):
         if self._h:

@@ -184,3 +184,20 @@ def test_lds_schedule_is_a_permutation_and_conflict_free(hip, name, block, free)
     if free:
         assert opt["conflicts"] == 0
     assert opt["words"] <= 65535
+
+
+@pytest.mark.parametrize("name,block", [("peg_16000_3_0.9.txt", 1024), ("4095.737.3.txt", 512),
+                                        ("1057.244.3.txt", 256), ("Frolov_1024_0.5.txt", 512)])
+def test_variable_pass_placement_keeps_the_schedule_valid(hip, name, block):
+    """vpass_place.cpp re-ranks variables within their LDS banks for the fused floating-point
+    min-sum kernel's variable pass.  It must leave a valid schedule (errors == 0: every variable
+    still alone on a word of its own bank, every check still visiting exactly its variables,
+    pad slots untouched -- so the check pass stays conflict free) and must not make the
+    modelled bank-conflict cycles of the variable pass worse; on the regular codes it removes
+    more than half of them."""
+    code = hip.Code.from_alist(code_path(name))
+    st = code.vpass_place_stats(block)
+    assert st["errors"] == 0
+    assert st["reads"] > 0 and 0 <= st["after"] <= st["before"]
+    if not name.startswith("Frolov"):
+        assert st["after"] < 0.5 * st["before"]
