@@ -517,7 +517,27 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nsg[r][w]));
         }
       };
-      if (wave_full) phase_a(std::integral_constant<int, CPT>{});
+      // after the last iteration only the verdict is wanted: the parity of the hard decisions
+      // (sign bits of the sums), not another set of messages
+      auto parity_only = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          unsigned pp = 0;
+#pragma unroll
+          for (int k = 0; k < RM; k += 2) {
+            const int s0 = *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
+            const int s1 = *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]);
+            pp = __builtin_amdgcn_bitop3_b32(pp, (unsigned)s0, (unsigned)s1, 0x96);
+          }
+          par[r] = (int)(pp >> 31);
+          bad |= par[r] ^ sbit[r];
+        }
+      };
+      if (t == a.max_iter + 1) {
+        if (wave_full) parity_only(std::integral_constant<int, CPT>{});
+        else parity_only(std::integral_constant<int, CPT - 1>{});
+      } else if (wave_full) phase_a(std::integral_constant<int, CPT>{});
       else phase_a(std::integral_constant<int, CPT - 1>{});
       const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : __syncthreads_or(bad);
       if (!any_bad) { it_done = t - 1; ok = 1; break; }
