@@ -300,6 +300,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
   const bool wave_full = __ballot(has[CPT - 1]) != 0;   // (wave-uniform) any check in the last round?
 
   const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const bool vec_in = (a.n & 3) == 0 && ((size_t)a.llr & 15) == 0;
   const fq_u4 *pos8 = (const fq_u4 *)a.pos;
 
   for (int i = a.dummy_base + tid; i < a.words; i += B) ffsum[i] = 1e30f;     // pad slots: sign 0, never a minimum
@@ -317,7 +318,21 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
     if (tid == 0) next_frame = atomicAdd(a.counter, 1);
     {
       const size_t base = (size_t)frame * a.n;
-      if (a.dt == 1) {
+      if (a.dt == 1 && vec_in) {
+        // four variables per thread and step: one 16-byte load of LLRs, one 8-byte load of positions
+        typedef float ff_f4 __attribute__((ext_vector_type(4)));
+        const ff_f4 *p4 = (const ff_f4 *)((const float *)a.llr + base);
+        const fq_u2 *pos4 = (const fq_u2 *)a.pos;
+        for (int i = tid; i < (a.n >> 2); i += B) {
+          const ff_f4 v = __builtin_nontemporal_load(p4 + i);
+          const fq_u2 w = pos4[i];
+          const float x0 = v.x + 0.0f, x1 = v.y + 0.0f, x2 = v.z + 0.0f, x3 = v.w + 0.0f;
+          ffsum[w.x & 0xffffu] = x0; q0L[w.x & 0xffffu] = x0;
+          ffsum[w.x >> 16] = x1; q0L[w.x >> 16] = x1;
+          ffsum[w.y & 0xffffu] = x2; q0L[w.y & 0xffffu] = x2;
+          ffsum[w.y >> 16] = x3; q0L[w.y >> 16] = x3;
+        }
+      } else if (a.dt == 1) {
         const float *p = (const float *)a.llr + base;
         for (int i = tid; i < a.n; i += B) { const float x = __builtin_nontemporal_load(p + i) + 0.0f; const int w = a.pos[i]; ffsum[w] = x; q0L[w] = x; }
       } else {
