@@ -304,6 +304,25 @@ int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, i
 int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
              int num_reads, int decode_mode, double *p_rec_given_sent, double *errors);
 
+/* main() of GFq_LDPC_NTT.c:641-703, the GF(2^p) Walsh-Hadamard program
+ *   GFq_LDPC_NTT [-iter num] <lap|bsc> NoiseLevel ParityMatrix        (:656-663)
+ * as a function: three experiments, SRand(j) for j = 1..3 (:681-695), each
+ * x[i] = Rand() % Q, s = enc(x), channel(x, y, level, logfna), dec(logfna, s,
+ * iteration, x); the three frames are decoded as one batch on the GPU.
+ * verdict[3] = dec()'s return value per experiment, 0 ("converged.") or -1
+ * ("failed."), which is all the program reports (:691-694); iters[3] (may be
+ * NULL) = iterations executed.  The reference fixes Q at compile time (-DLog2Q);
+ * here it is the field order in the matrix file's header.  Its -iter default
+ * is 1000 (:647).  lap()'s statistics printout (:357-364) is not produced. */
+int GFq_LDPC_NTT(int iteration, const char *channel, double level, const char *matrix_file,
+                 int32_t *verdict, int32_t *iters);
+/* The inputs of one such experiment (:683-687) for SRand(seed): x[n], s[m], the
+ * side information y[n] and logfna[n][q] (log2 domain, Q.14, float2fix :177-184).
+ * Rand() is a 31-bit LCG (:163-167), so these are the reference's values exactly.
+ * Host only; needs no GPU. */
+int GFq_LDPC_NTT_experiment(const char *matrix_file, int seed, const char *channel, double level,
+                            int32_t *x, int32_t *s, int32_t *y, int32_t *logfna);
+
 /* Seed of the library's Monte-Carlo generator (the reference uses
  * srand(time(NULL)); 0 = seed from the clock like the reference). */
 void ldpc_set_seed(uint64_t seed);

@@ -381,3 +381,132 @@ extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials
   }
   return LDPC_OK;
 }
+
+// ---------------------------------------------------------------------------
+// GFq_LDPC_NTT.c's program: main() :641-703 runs three experiments, SRand(j) for
+// j = 1..3, on a 31-bit LCG (:155-167) that is the same on every platform, so
+// unlike the rand()-seeded harnesses above its inputs can be regenerated exactly.
+namespace {
+
+struct Lcg31 {   // Rand(), GFq_LDPC_NTT.c:163-167
+  uint32_t r;
+  uint32_t next() { return r = (77u * r + 1243u) & 0x7fffffffu; }
+};
+
+// the program's own log2 (:153, :194): a quotient of natural logarithms, not libm's log2()
+inline double ntt_log2(double v) { return std::log(v) / std::log(2.0); }
+
+// float2fix(), GFq_LDPC_NTT.c:177-184, DECI = 14
+inline int32_t ntt_fix(double v) {
+  return v >= 0 ? (int32_t)(v * 16384.0 + 0.5) : -(int32_t)((-v) * 16384.0 + 0.5);
+}
+
+// bsc(), GFq_LDPC_NTT.c:278-315: exactly round(p * n * log2 q) distinct bit flips
+void ntt_bsc(Lcg31 &g, int n, int Q, int log2q, const int32_t *x, int32_t *y, double p, int32_t *logfna) {
+  const int len = log2q * n;
+  int todo = (int)(len * p + 0.5);
+  p = todo / (double)len;
+  std::vector<int32_t> err(n, 0);
+  while (todo) {
+    const int i = (int)(g.next() % (uint32_t)len);
+    const int bit = 1 << (i % log2q);
+    if (err[i / log2q] & bit) continue;
+    err[i / log2q] |= bit;
+    todo--;
+  }
+  for (int i = 0; i < n; i++) y[i] = x[i] ^ err[i];
+  const double lp = ntt_log2(p), l1p = ntt_log2(1 - p);
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < Q; a++) {
+      double logprod = 0;
+      for (int j = 1; j < Q; j <<= 1) logprod += ((a & j) == (y[i] & j)) ? l1p : lp;
+      logfna[(size_t)i * Q + a] = ntt_fix(logprod);
+    }
+}
+
+// lap(), GFq_LDPC_NTT.c:320-356 (its statistics printout, :357-364, is not reproduced)
+void ntt_lap(Lcg31 &g, int n, int Q, const int32_t *x, int32_t *y, double stddev, int32_t *logfna) {
+  std::vector<double> lf(Q);
+  for (int i = 0; i < n; i++) {
+    const double u2 = (g.next() + 1) * (1.0 / (0x7fffffffUL + 1.0));
+    const int logu2 = (int)std::floor(ntt_log2(u2) * stddev + .5);
+    y[i] = (g.next() & 1) == 0 ? x[i] - logu2 : x[i] + logu2;
+    if (y[i] < 0) y[i] = 0;
+    else if (y[i] >= Q) y[i] = Q - 1;
+    double sum = 0;
+    for (int a = 0; a < Q; a++) {
+      lf[a] = y[i] == a ? -0.5 / stddev : -(std::abs(y[i] - a) - 0.0413) / stddev;
+      sum += std::pow(2.0, lf[a]);
+    }
+    sum = ntt_log2(sum);
+    for (int a = 0; a < Q; a++) logfna[(size_t)i * Q + a] = ntt_fix(lf[a] - sum);
+  }
+}
+
+int ntt_channel_id(const char *channel) {
+  if (channel && strcmp(channel, "bsc") == 0) return 0;
+  if (channel && strcmp(channel, "lap") == 0) return 1;
+  ldpc_set_error("GFq_LDPC_NTT: please specify 'lap' or 'bsc'");   // :666
+  return -1;
+}
+
+int ntt_experiment(const ldpc_code *code, int seed, int ch, double level, int32_t *x, int32_t *s, int32_t *y,
+                   int32_t *logfna) {
+  const int n = ldpc_code_n(code), Q = ldpc_code_q(code);
+  int log2q = 0;
+  while ((1 << log2q) < Q) log2q++;
+  if ((1 << log2q) != Q) {
+    ldpc_set_error("GFq_LDPC_NTT: the field order must be a power of two");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  Lcg31 g{(uint32_t)seed};                                       // SRand(j), :683
+  for (int i = 0; i < n; i++) x[i] = (int32_t)(g.next() % (uint32_t)Q);   // :684-685
+  int rc = ldpc_code_syndrome(code, x, s);                       // enc(x, s), :686
+  if (rc) return rc;
+  if (ch == 0) ntt_bsc(g, n, Q, log2q, x, y, level, logfna);     // channel(x, y, error, logfna), :687
+  else ntt_lap(g, n, Q, x, y, level, logfna);
+  return LDPC_OK;
+}
+
+}  // namespace
+
+extern "C" int GFq_LDPC_NTT_experiment(const char *matrix_file, int seed, const char *channel, double level,
+                                       int32_t *x, int32_t *s, int32_t *y, int32_t *logfna) {
+  if (!matrix_file || !x || !s || !y || !logfna) return LDPC_ERR_ARG;
+  const int ch = ntt_channel_id(channel);
+  if (ch < 0) return LDPC_ERR_ARG;
+  ldpc_code *code = nullptr;
+  int rc = ldpc_code_load_alist(matrix_file, &code);
+  if (rc) return rc;
+  rc = ntt_experiment(code, seed, ch, level, x, s, y, logfna);
+  ldpc_code_free(code);
+  return rc;
+}
+
+extern "C" int GFq_LDPC_NTT(int iteration, const char *channel, double level, const char *matrix_file,
+                            int32_t *verdict, int32_t *iters) {
+  if (!verdict || iteration < 0) return LDPC_ERR_ARG;
+  const int ch = ntt_channel_id(channel);
+  if (ch < 0) return LDPC_ERR_ARG;
+  ldpc_code *code;
+  ldpc_decoder *dec;
+  int rc = get_decoder(matrix_file, LDPC_ALG_GF2P_WHT, &code, &dec);
+  if (rc) return rc;
+  const int n = ldpc_code_n(code), m = ldpc_code_m(code), Q = ldpc_code_q(code);
+  std::vector<int32_t> x(n), s(m), y(n), logfna((size_t)3 * n * Q), status(3), it(3);
+  std::vector<uint8_t> synd((size_t)3 * m);
+  for (int j = 1; j <= 3; j++) {                                 // :681
+    rc = ntt_experiment(code, j, ch, level, x.data(), s.data(), y.data(), &logfna[(size_t)(j - 1) * n * Q]);
+    if (rc) return rc;
+    for (int k = 0; k < m; k++) synd[(size_t)(j - 1) * m + k] = (uint8_t)s[k];
+  }
+  // the three dec(logfna, s, iteration, x) calls of :692 as one batch
+  rc = ldpc_decode_batch(dec, 3, logfna.data(), LDPC_DT_I32, synd.data(), iteration, nullptr, it.data(), nullptr,
+                         status.data(), nullptr);
+  if (rc) return rc;
+  for (int j = 0; j < 3; j++) {
+    verdict[j] = status[j] ? -1 : 0;                             // dec() returns 0 (:531) or -1 (:543)
+    if (iters) iters[j] = it[j];
+  }
+  return LDPC_OK;
+}

@@ -111,6 +111,8 @@ def load_library():
     L.test_code_B.argtypes = [ip, ip, C.c_double, cp, dp]
     L.GFq_LDPC.argtypes = [cp, ip, ip, ip, ip, ip, dp, dp]
     L.test_code_B_MSDP.argtypes = [cp, ip, ip, ip, ip, dp, dp]
+    L.GFq_LDPC_NTT.argtypes = [ip, cp, C.c_double, cp, vp, vp]
+    L.GFq_LDPC_NTT_experiment.argtypes = [cp, ip, cp, C.c_double, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -123,3 +123,24 @@ def test_gfq_ldpc_harness(hip):
     rc = L.GFq_LDPC(code_path("peg_4376_4_0.9_NB.txt").encode(), 3, 4, 0, 1, 1,
                     conf2.ctypes.data_as(C.POINTER(C.c_double)), err)
     assert rc == -6
+
+
+@pytest.mark.parametrize("q,fname,channel,level", [(4, "q4.sp.9000.6000.4500.1", "bsc", 0.08),
+                                                   (8, "q8.sp.6000.4000.3000.1", "lap", 0.5)])
+def test_GFq_LDPC_NTT_program(hip, q, fname, channel, level):
+    """GFq_LDPC_NTT(): the reference program's main() (:641-703) on its own usage examples
+    (:660-661) with -iter 50; verdicts equal those of the compiled reference
+    (tests/golden/ref_ntt_q*.npz rows 0..2: "converged." three times)."""
+    g = np.load(os.path.join(GOLDEN, f"ref_ntt_q{q}.npz"))
+    L = hip.load_library()
+    verdict = np.full(3, 7, np.int32)
+    iters = np.zeros(3, np.int32)
+    rc = L.GFq_LDPC_NTT(int(g["maxit"]), channel.encode(), level, code_path(fname).encode(),
+                        verdict.ctypes.data, iters.ctypes.data)
+    assert rc == 0, L.ldpc_last_error()
+    assert np.array_equal(verdict, g["rc"][:3])
+    assert ((iters >= 1) & (iters <= int(g["maxit"]))).all()
+    # one iteration is not enough for any of them: dec() returns -1 (:543)
+    rc = L.GFq_LDPC_NTT(1, channel.encode(), level, code_path(fname).encode(), verdict.ctypes.data, None)
+    assert rc == 0 and (verdict == -1).all()
+    assert L.GFq_LDPC_NTT(5, b"awgn", level, code_path(fname).encode(), verdict.ctypes.data, None) < 0

@@ -201,3 +201,31 @@ def test_variable_pass_placement_keeps_the_schedule_valid(hip, name, block):
     assert st["reads"] > 0 and 0 <= st["after"] <= st["before"]
     if not name.startswith("Frolov"):
         assert st["after"] < 0.5 * st["before"]
+
+
+@pytest.mark.parametrize("q,fname,channel,level", [(4, "q4.sp.9000.6000.4500.1", "bsc", 0.08),
+                                                   (8, "q8.sp.6000.4000.3000.1", "lap", 0.5)])
+def test_ntt_program_experiments_match_reference(hip, q, fname, channel, level):
+    """GFq_LDPC_NTT_experiment (host only) regenerates the inputs of the reference program's
+    three experiments (main(), GFq_LDPC_NTT.c:681-687: LCG source word, enc(), bsc()/lap())
+    exactly: compared with x, s, logfna captured from the compiled reference
+    (tests/golden/ref_ntt_q*.npz, rows 0..2 = seeds 1..3)."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, f"ref_ntt_q{q}.npz"))
+    L = hip.load_library()
+    n, m = g["x"].shape[1], g["s"].shape[1]
+    for seed in (1, 2, 3):
+        x = np.zeros(n, np.int32); s = np.zeros(m, np.int32); y = np.zeros(n, np.int32)
+        lf = np.zeros((n, q), np.int32)
+        rc = L.GFq_LDPC_NTT_experiment(code_path(fname).encode(), seed, channel.encode(), level,
+                                       x.ctypes.data, s.ctypes.data, y.ctypes.data, lf.ctypes.data)
+        assert rc == 0, L.ldpc_last_error()
+        assert np.array_equal(x, g["x"][seed - 1])
+        assert np.array_equal(s, g["s"][seed - 1])
+        assert np.array_equal(lf, g["logfna"][seed - 1])
+        assert (y != x).any() and ((y >= 0) & (y < q)).all()
+    # argument errors come back as codes, not exit()/usage text
+    assert L.GFq_LDPC_NTT_experiment(code_path(fname).encode(), 1, b"awgn", level, x.ctypes.data, s.ctypes.data,
+                                     y.ctypes.data, lf.ctypes.data) < 0
+    assert L.GFq_LDPC_NTT_experiment(code_path("peg_4376_4_0.9_NB.txt").encode(), 1, b"bsc", level, x.ctypes.data,
+                                     s.ctypes.data, y.ctypes.data, lf.ctypes.data) < 0     # GF(13): not 2^p
