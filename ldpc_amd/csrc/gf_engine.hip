@@ -300,6 +300,87 @@ __global__ __launch_bounds__(64) void gfq_cn_kernel(GGraph g, int nfg, const dou
   }
 }
 
+// The same check node with the sigma / rho recursions carried as probabilities.
+// Every logqa row is a normalised pmf (GFq_LDPC.c:446-457), so each sigma_k and
+// rho_k is the pmf of a partial check sum: the reference's
+//   log(sum_t exp(logsigma[s] + logqa[t]))           (:377-382, :395-400, :415-420)
+// is log(sum_t sigma[s] * qa[t]) with sigma = exp(logsigma), qa = exp(logqa).
+// Keeping sigma and rho linear between the steps needs one exp per (edge, symbol)
+// and one log per extrinsic value instead of q exps for each of them; the terms
+// are added in the reference's order (t ascending).  Values agree with the
+// literal kernel above to rounding (a few ulp of binary64), not bit for bit.
+//
+// The pmfs a lane convolves live in LDS rows of 64 doubles (lane l's own value at
+// [l]): rho_k for every k, the running sigma and exp(logqa) of the current edge,
+// so a term of a convolution is two ds_read_b64 (one of them a broadcast within
+// the frame's lane group) and one fma; s = a - t*h walks down by h per term in a
+// prime field and is a ^ (t*h) in GF(2^p).  QT = field order at compile time
+// (0: any), which unrolls the t loops.
+template <int QT>
+__global__ __launch_bounds__(64) void gfq_cn_lin_kernel(GGraph g, int nfg, const double *__restrict__ qa,
+                                                        double *__restrict__ ra,
+                                                        const uint8_t *__restrict__ synd) {
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  const int Q = QT ? QT : g.Q;
+  const int l = threadIdx.x & 63;
+  const int grp = l / Q;
+  const bool live = grp < g.G;
+  const int a = live ? l - grp * Q : 0;
+  const int base = live ? grp * Q : 0;
+  const int j = blockIdx.x / nfg, fg = blockIdx.x - j * nfg;
+  const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
+  const int f = fg * g.G + grp;
+  const int z = (synd && live) ? synd[(size_t)j * g.Fpad + f] : 0;
+  const bool pow2 = g.pow2 != 0;
+  double *rho = lds_d;            // [dc][64]
+  double *S = rho + dc * 64;      // sigma_{k-1}
+  double *P = S + 64;             // exp(logqa) of the current edge
+  // sum_t A[start - t*h] * B[t], t ascending
+  auto conv = [&](const double *A, const double *B, int start, int h) -> double {
+    double sum = 0;
+    if (pow2) {
+#pragma unroll
+      for (int t = 0; t < Q; t++) sum += A[base + (start ^ g.mul[t * Q + h])] * B[base + t];
+    } else {
+      int s = start;
+#pragma unroll
+      for (int t = 0; t < Q; t++) {
+        sum += A[base + s] * B[base + t];
+        s -= h;
+        s += s < 0 ? Q : 0;
+      }
+    }
+    return sum;
+  };
+  for (int k = dc - 1; k >= 1; k--) {
+    const int e = p0 + k;
+    const int h = g.hval[e];
+    P[l] = live ? exp(qa[((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + l]) : 0.0;
+    __syncthreads();
+    const double r = k == dc - 1 ? P[base + g.mul[a * Q + g.hinv[e]]]      // rho[a*h] = qa[a]
+                                 : conv(rho + (k + 1) * 64, P, a, h);
+    rho[k * 64 + l] = r;
+    __syncthreads();
+  }
+  for (int k = 0; k < dc; k++) {
+    const int e = p0 + k;
+    const int h = g.hval[e];
+    const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + l;
+    P[l] = live ? exp(qa[off]) : 0.0;
+    __syncthreads();
+    const int zah = gf_sub(g, z, g.mul[a * Q + h]);
+    double out;
+    if (k == 0) out = dc > 1 ? log(rho[64 + base + zah]) : 0.0;
+    else if (k == dc - 1) out = log(S[base + zah]);
+    else out = log(conv(S, rho + (k + 1) * 64, zah, 1));
+    if (live) ra[off] = out;
+    const double ns = k == 0 ? P[base + g.mul[a * Q + g.hinv[e]]]         // sigma[a*h] = qa[a]
+                             : conv(S, P, a, h);
+    __syncthreads();
+    S[l] = ns;
+  }
+}
+
 // GFq_LDPC.c:426-457
 __global__ __launch_bounds__(256) void gfq_vn_kernel(GGraph g, int nfg, const double *__restrict__ fna,
                                                      const double *__restrict__ ra, double *__restrict__ qa,
@@ -476,7 +557,7 @@ struct GfEngine : Engine {
           ldpc_set_error("q is neither prime nor a power of two");
           return LDPC_ERR_UNSUPPORTED;
         }
-    const size_t lds = (size_t)rmax * 64 * 8;
+    const size_t lds = (size_t)(rmax + 2) * 64 * 8;
     if (lds > 160 * 1024) {
       ldpc_set_error("row weight too large for the LDS-staged GF check node");
       return LDPC_ERR_UNSUPPORTED;
@@ -536,8 +617,18 @@ struct GfEngine : Engine {
         HIPCHK(hipFuncSetAttribute((const void *)gf2p_cn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
       else
+      {
         HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+      }
     }
     return LDPC_OK;
   }
@@ -614,18 +705,30 @@ struct GfEngine : Engine {
                        fna.as<T>(), qa.as<T>());
     LAUNCHCHK("gf_init_kernel");
 
-    const size_t lds = (size_t)rmax * 64 * 8;
+    const size_t lds = (size_t)(rmax + 2) * 64 * 8;
     const unsigned vn_blocks = (unsigned)(((size_t)n * nfg + 3) / 4);
     int executed = 0;
     const bool early = opts.early_exit != 0;
+    // GFQ_DIRECT: cn_variant 1 = the reference's log-sum-exp recursions term by term
+    // (gfq_cn_kernel); default = the same recursions on probabilities (gfq_cn_lin_kernel)
+    int variant = opts.cn_variant;
+    if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) variant = atoi(e);
+    const bool literal_cn = variant == 1;
+    (void)literal_cn;
     for (int t = 0; t < max_iter; t++) {
       prof_begin(K_CN, st);
       if constexpr (WHT)
         hipLaunchKernelGGL(gf2p_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, tab, nfg,
                            qa.as<int>(), ra.as<int>(), sy);
-      else
+      else if (literal_cn)
         hipLaunchKernelGGL(gfq_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg,
                            qa.as<double>(), ra.as<double>(), sy);
+      else {
+        auto kern = Q == 13 ? gfq_cn_lin_kernel<13> : Q == 4 ? gfq_cn_lin_kernel<4> : Q == 8 ? gfq_cn_lin_kernel<8>
+                                                                                            : gfq_cn_lin_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg, qa.as<double>(),
+                           ra.as<double>(), sy);
+      }
       LAUNCHCHK("gf cn kernel");
       prof_end(st);
       prof_begin(K_VN, st);

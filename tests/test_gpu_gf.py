@@ -103,6 +103,31 @@ def test_gfq_direct_vs_oracle(hip, oracle, fname, q, F, perr, it):
     assert any(r["rc"] == 0 for r in ref) and any(r["rc"] != 0 for r in ref)
 
 
+@pytest.mark.parametrize("fname,q,F,perr", [("peg_4376_4_0.9_NB.txt", 13, 9, 0.012),
+                                            ("q4.sp.9000.6000.4500.1", 4, 16, 0.12)])
+def test_gfq_direct_probability_domain_equals_literal(hip, fname, q, F, perr):
+    """The default check-node kernel carries sigma/rho as probabilities (one exp per edge
+    symbol); cn_variant=1 evaluates the reference's log-sum-exp (GFq_LDPC.c:377-382) term by
+    term.  Same decoded symbols, iteration counts and verdicts."""
+    code = hip.Code.from_alist(code_path(fname))
+    rng = np.random.default_rng(5)
+    conf = _conf_matrix(q, perr)
+    post = conf / conf.sum(axis=1, keepdims=True)                   # P(sent | rec), uniform prior
+    x = rng.integers(0, q, size=(F, code.n))
+    u = rng.random((F, code.n))
+    pe = np.where(np.arange(F) % 3 == 2, 5 * perr, perr)[:, None]
+    y = np.where(u < pe / 2, (x + 1) % q, np.where(u < pe, (x - 1) % q, x))
+    logfna = np.log(np.maximum(post[y], 3.7e-44))                   # [F][n][q], floor exp(-100)
+    s = np.stack([code.syndrome(x[f]) for f in range(F)]).astype(np.uint8)
+    outs = []
+    for variant in (0, 1):
+        dec = hip.Decoder(code, hip.ALG.GFQ_DIRECT, max_frames=8, cn_variant=variant)
+        outs.append(dec.decode(np.ascontiguousarray(logfna), s, 10))
+    for k in ("status", "iters", "bits", "synd"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert (outs[0]["status"] == 0).any() and (outs[0]["status"] != 0).any()
+
+
 def test_gfq_ldpc_harness(hip):
     """GFq_LDPC() (GFq_LDPC.c:540-655) through the reference-shaped entry point."""
     import ctypes as C

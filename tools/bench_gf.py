@@ -23,7 +23,10 @@ def main():
              ("q4.sp.9000.6000.4500.1", "GFQ_DIRECT", DT.F32, torch.float32, 2048),
              ("peg_4376_4_0.9_NB.txt", "GFQ_DIRECT", DT.F32, torch.float32, 1024)]
     print(f"{'code':26s} {'alg':11s} {'q':>3s} {'frames':>6s} {'ms/pass':>9s} {'Msym/s':>9s} {'info Gbit/s':>11s}")
+    want = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, alg, dt, tdt, F in cases:
+        if want not in name + alg:
+            continue
         code = ldpc_amd.Code.from_alist(os.path.join(CODES, name))
         n, m, q = code.n, code.m, code.q
         gen = torch.Generator(device=dev)
@@ -47,8 +50,13 @@ def main():
             step()
         torch.cuda.synchronize()
         dt_s = (time.perf_counter() - t0) / 3
+        dec.profile(True)
+        step()
+        ms_k, cnt_k = dec.profile_read()
+        dec.profile(False)
         print(f"{name:26s} {alg:11s} {q:3d} {F:6d} {dt_s * 1e3:9.3f} {n * F / dt_s / 1e6:9.1f} "
-              f"{(n - m) * np.log2(q) * F / dt_s / 1e9:11.3f}", flush=True)
+              f"{(n - m) * np.log2(q) * F / dt_s / 1e9:11.3f}   per pass: check {ms_k[1]:.1f} ms, variable {ms_k[0]:.1f} ms",
+              flush=True)
 
 
 if __name__ == "__main__":
