@@ -316,7 +316,14 @@ __global__ __launch_bounds__(64) void gfq_cn_kernel(GGraph g, int nfg, const dou
 // the frame's lane group) and one fma; s = a - t*h walks down by h per term in a
 // prime field and is a ^ (t*h) in GF(2^p).  QT = field order at compile time
 // (0: any), which unrolls the t loops.
-template <int QT>
+//
+// SPILL: a check of weight dc holds dc rho rows, 512 B each, for the whole forward
+// sweep; at dc = 63 that is 32 KB per wavefront and five wavefronts per CU.  With
+// SPILL the backward sweep parks rho_k in the check's own output rows ra[j][k]
+// instead (same shape, and ra[j][k] only receives its extrinsic value at forward
+// step k, after rho_k was last needed at step k-1), LDS keeps three rows, and the
+// CU fills up.  Same values either way.
+template <int QT, bool SPILL>
 __global__ __launch_bounds__(64) void gfq_cn_lin_kernel(GGraph g, int nfg, const double *__restrict__ qa,
                                                         double *__restrict__ ra,
                                                         const uint8_t *__restrict__ synd) {
@@ -332,9 +339,10 @@ __global__ __launch_bounds__(64) void gfq_cn_lin_kernel(GGraph g, int nfg, const
   const int f = fg * g.G + grp;
   const int z = (synd && live) ? synd[(size_t)j * g.Fpad + f] : 0;
   const bool pow2 = g.pow2 != 0;
-  double *rho = lds_d;            // [dc][64]
-  double *S = rho + dc * 64;      // sigma_{k-1}
-  double *P = S + 64;             // exp(logqa) of the current edge
+  double *rho = lds_d;                        // [dc][64], or one row (rho_{k+1}) with SPILL
+  double *S = rho + (SPILL ? 64 : dc * 64);   // sigma_{k-1}
+  double *P = S + 64;                         // exp(logqa) of the current edge
+  const size_t fo = (size_t)fg * g.G * Q + l;
   // sum_t A[start - t*h] * B[t], t ascending
   auto conv = [&](const double *A, const double *B, int start, int h) -> double {
     double sum = 0;
@@ -355,24 +363,33 @@ __global__ __launch_bounds__(64) void gfq_cn_lin_kernel(GGraph g, int nfg, const
   for (int k = dc - 1; k >= 1; k--) {
     const int e = p0 + k;
     const int h = g.hval[e];
-    P[l] = live ? exp(qa[((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + l]) : 0.0;
+    const size_t off = (size_t)e * g.Fpad * Q + fo;
+    P[l] = live ? exp(qa[off]) : 0.0;
     __syncthreads();
     const double r = k == dc - 1 ? P[base + g.mul[a * Q + g.hinv[e]]]      // rho[a*h] = qa[a]
-                                 : conv(rho + (k + 1) * 64, P, a, h);
-    rho[k * 64 + l] = r;
+                                 : conv(SPILL ? rho : rho + (k + 1) * 64, P, a, h);
+    if (SPILL) {
+      __syncthreads();
+      rho[l] = r;
+      if (live) ra[off] = r;
+    } else {
+      rho[k * 64 + l] = r;
+    }
     __syncthreads();
   }
   for (int k = 0; k < dc; k++) {
     const int e = p0 + k;
     const int h = g.hval[e];
-    const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * Q + l;
+    const size_t off = (size_t)e * g.Fpad * Q + fo;
     P[l] = live ? exp(qa[off]) : 0.0;
+    if (SPILL && k + 1 < dc) rho[l] = live ? ra[off + (size_t)g.Fpad * Q] : 0.0;   // rho_{k+1}, parked in ra[j][k+1]
     __syncthreads();
+    const double *rn = SPILL ? rho : rho + (k + 1) * 64;
     const int zah = gf_sub(g, z, g.mul[a * Q + h]);
     double out;
-    if (k == 0) out = dc > 1 ? log(rho[64 + base + zah]) : 0.0;
+    if (k == 0) out = dc > 1 ? log(rn[base + zah]) : 0.0;
     else if (k == dc - 1) out = log(S[base + zah]);
-    else out = log(conv(S, rho + (k + 1) * 64, zah, 1));
+    else out = log(conv(S, rn, zah, 1));
     if (live) ra[off] = out;
     const double ns = k == 0 ? P[base + g.mul[a * Q + g.hinv[e]]]         // sigma[a*h] = qa[a]
                              : conv(S, P, a, h);
@@ -620,14 +637,7 @@ struct GfEngine : Engine {
       {
         HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)gfq_cn_lin_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+        // (the probability-domain kernel parks rho in HBM for heavy checks: it never needs > 64 KB)
       }
     }
     return LDPC_OK;
@@ -723,9 +733,14 @@ struct GfEngine : Engine {
       else if (literal_cn)
         hipLaunchKernelGGL(gfq_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg,
                            qa.as<double>(), ra.as<double>(), sy);
-      else {
-        auto kern = Q == 13 ? gfq_cn_lin_kernel<13> : Q == 4 ? gfq_cn_lin_kernel<4> : Q == 8 ? gfq_cn_lin_kernel<8>
-                                                                                            : gfq_cn_lin_kernel<0>;
+      else if (rmax > 8) {   // heavy checks: rho parked in ra, three LDS rows
+        auto kern = Q == 13 ? gfq_cn_lin_kernel<13, true> : Q == 4 ? gfq_cn_lin_kernel<4, true>
+                  : Q == 8  ? gfq_cn_lin_kernel<8, true>  : gfq_cn_lin_kernel<0, true>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)m * nfg)), dim3(64), 3 * 64 * 8, st, gg, nfg,
+                           qa.as<double>(), ra.as<double>(), sy);
+      } else {
+        auto kern = Q == 13 ? gfq_cn_lin_kernel<13, false> : Q == 4 ? gfq_cn_lin_kernel<4, false>
+                  : Q == 8  ? gfq_cn_lin_kernel<8, false>  : gfq_cn_lin_kernel<0, false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg, qa.as<double>(),
                            ra.as<double>(), sy);
       }
