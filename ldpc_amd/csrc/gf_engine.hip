@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void gf2p_cn_kernel(GGraph g, WTab tab, int nfg
   const Lane L = lane_of(g);
   const int j = blockIdx.x / nfg, fg = blockIdx.x - j * nfg;
   const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
-  int *fq = lds_i;              // [dc][64] scaled |WHT| value
+  int *fq = lds_i;              // [dc][64] Flog of the scaled |WHT| value (looked up once, used twice)
   int *ng = lds_i + 64 * dc;    // [dc][64] its sign
   const int f = fg * g.G + L.g;
   const int z = (synd && L.active) ? synd[(size_t)j * g.Fpad + f] : 0;
@@ -175,14 +175,15 @@ __global__ __launch_bounds__(64) void gf2p_cn_kernel(GGraph g, WTab tab, int nfg
     if (y < 0) { y = -y; neg = 1; }
     sgnsum ^= neg;
     y = (y + (1 << (half - 1))) >> half;
-    fq[k * 64 + L.l] = y;
+    const int lg = w_flog(tab, y);
+    fq[k * 64 + L.l] = lg;
     ng[k * 64 + L.l] = neg;
-    logprod += w_flog(tab, y);
+    logprod += lg;
   }
   for (int k = 0; k < dc; k++) {
     const int e = p0 + k;
     const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * g.Q + L.l;
-    int r = w_fexp(tab, logprod - w_flog(tab, fq[k * 64 + L.l]) + g.log2q * W_FMUL);
+    int r = w_fexp(tab, logprod - fq[k * 64 + L.l] + g.log2q * W_FMUL);
     if (ng[k * 64 + L.l] != sgnsum) r = -r;
     r = wht_lanes(r, L.a, g.log2q);
     // logra[a] = Flog(fRa[z - a*h])
