@@ -48,7 +48,10 @@ struct Rng {
 Rng take_rng() {   // one independent stream per entry-point call
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_seeded) {
-    g_state = clock_seed();
+    // LDPC_HIP_SEED: what ldpc_set_seed() does, for callers that cannot call it (the C drivers)
+    const char *e = getenv("LDPC_HIP_SEED");
+    const uint64_t v = e ? strtoull(e, nullptr, 0) : 0;
+    g_state = v ? v : clock_seed();
     g_seeded = true;
   }
   Rng r{g_state};

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, code_path
+from conftest import GOLDEN, ROOT, code_path
 
 pytestmark = pytest.mark.gpu
 
@@ -142,3 +142,20 @@ def test_python_run_api(hip, oracle):
     assert it is True and not cw.any()
     out = ldpc_decode.run_batch(path, np.full((5, oc.n), 2.5), 10)
     assert (out["status"] == 0).all() and not out["bits"].any()
+
+
+def test_plain_c_driver_programs():
+    """The reference's two stand-alone programs rebuilt as plain-C callers of libldpc_hip
+    (tools/drivers, gcc): test_code_no_mex_B's main() arguments (:386) and GFq_LDPC_NTT's
+    usage example (:661), whose three verdict lines are those of the compiled reference."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "drivers", "bin", "test_code_no_mex_B")
+    r = subprocess.run([exe, code_path("4095.737.3.txt"), "30", "4", "0.01"], capture_output=True, text=True,
+                       timeout=120, env=dict(os.environ, LDPC_HIP_SEED="7"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "Errors = 0.000000\nUndetected Errors = 0.000000\n"
+    exe = os.path.join(ROOT, "tools", "drivers", "bin", "GFq_LDPC_NTT")
+    r = subprocess.run([exe, "-iter", "50", "bsc", "0.08", code_path("q4.sp.9000.6000.4500.1")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "converged.\nconverged.\nconverged.\n"

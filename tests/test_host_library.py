@@ -229,3 +229,22 @@ def test_ntt_program_experiments_match_reference(hip, q, fname, channel, level):
                                      y.ctypes.data, lf.ctypes.data) < 0
     assert L.GFq_LDPC_NTT_experiment(code_path("peg_4376_4_0.9_NB.txt").encode(), 1, b"bsc", level, x.ctypes.data,
                                      s.ctypes.data, y.ctypes.data, lf.ctypes.data) < 0     # GF(13): not 2^p
+
+
+def test_c_drivers_fail_loudly_without_a_gpu():
+    """The plain-C driver programs (gcc, no HIP headers) link against the library; where no
+    HIP device exists they exit non-zero with the library's message -- no CPU decode path."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_entry_points.py")
+    exe = os.path.join(ROOT, "tools", "drivers", "bin", "test_code_no_mex_B")
+    assert os.path.exists(exe), "run __graft_entry__.build() (make -C tools/drivers)"
+    r = subprocess.run([exe, code_path("4095.737.3.txt")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and r.stdout == ""
+    exe = os.path.join(ROOT, "tools", "drivers", "bin", "GFq_LDPC_NTT")
+    r = subprocess.run([exe, "bsc", "0.08", code_path("q4.sp.9000.6000.4500.1")], capture_output=True, text=True,
+                       timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout == ""
+    r = subprocess.run([exe, "bsc"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and r.stderr.startswith("usage:")
