@@ -144,6 +144,23 @@ def test_python_run_api(hip, oracle):
     assert (out["status"] == 0).all() and not out["bits"].any()
 
 
+@pytest.mark.parametrize("tag,fname", [("c204", "204.33.484.txt"), ("small", "small_code.txt")])
+def test_python_run_api_vs_reference_vectors(hip, tag, fname):
+    """ldpc_decode.run(H, LLR, max_iter, precheck=True) against the outputs of the reference's
+    parallel.run (tests/golden/python_run.npz): decoded word (n,1), and the iteration slot --
+    True when the input already satisfies H, the 1-based iteration, or False."""
+    from ldpc_amd import ldpc_decode
+    from ldpc_amd.alist import alist_to_mat
+    g = np.load(os.path.join(GOLDEN, "python_run.npz"))
+    H = alist_to_mat(code_path(fname))
+    maxit = int(g[tag + "_maxit"])
+    for llr, cw, it in zip(g[tag + "_llr"], g[tag + "_cw"], g[tag + "_iters"]):
+        got_cw, got_it, secs = ldpc_decode.run(H, llr, maxit, precheck=True)
+        assert got_cw.shape == (H.shape[1], 1) and np.array_equal(got_cw[:, 0], cw)
+        want = True if it == 0 else (False if it < 0 else int(it))
+        assert got_it is want if isinstance(want, bool) else (got_it == want and got_it is not True)
+
+
 def test_plain_c_driver_programs():
     """The reference's two stand-alone programs rebuilt as plain-C callers of libldpc_hip
     (tools/drivers, gcc): test_code_no_mex_B's main() arguments (:386) and GFq_LDPC_NTT's
