@@ -226,9 +226,25 @@ template <typename A> struct CnStateMin {
   __device__ __forceinline__ A others(A a) const { return a == m1 ? m2 : m1; }
 };
 
-__device__ __forceinline__ float spa_logtanh2(float a) { return logf(tanhf(a * 0.5f)); }
+// logtanh2() / atanh2(exp()) of test_code_B_float.c:20-27.  binary64 is the reference's literal
+// statement.  The literal formula in binary32 saturates at |LLR| ~ 17 (tanhf -> 1, log -> 0, the
+// next atanh2(1) = inf and inf - inf = NaN in the variable pass; binary64 gets there only at
+// ~37), which no DVB-S2 frame survives.  So binary32 evaluates the SAME two functions without
+// the cancellation: log tanh(a/2) = -2 atanh(e^-a) by its series once a > 3, and
+// 2 atanh(e^x) with 1 - e^x from the series of -expm1(x) above -0.1 and the atanh series
+// below -3; in between the literal form is accurate.  Values at 0, -inf and NaN stay the
+// reference's.
+__device__ __forceinline__ float spa_logtanh2(float a) {
+  if (a > 3.0f) { const float t = expf(-a), t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
+  return logf(tanhf(a * 0.5f));
+}
 __device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
-__device__ __forceinline__ float spa_atanh2exp(float x) { float e = expf(x); return logf((1.0f + e) / (1.0f - e)); }
+__device__ __forceinline__ float spa_atanh2exp(float x) {
+  const float e = expf(x);
+  if (x < -3.0f) { const float e2 = e * e; return 2.0f * e * (1.0f + e2 * (1.0f / 3.0f + e2 * 0.2f)); }
+  if (x > -0.1f) return logf((1.0f + e) / (fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
+  return logf((1.0f + e) / (1.0f - e));
+}
 __device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
 
 // Flogtanh / Fgallag (test_code_B.c:76-90)
@@ -280,7 +296,10 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
     }
   } else if constexpr (ALG == ALG_SPA) {
     // test_code_B_float.c:159-178
-    acc lp[V];
+    // logprod is summed in binary64 whatever the message type, as the reference does: the
+    // leave-one-out below is a subtraction, and a binary32 sum absorbs the confident edges'
+    // tiny terms next to one weak edge (difference 0 -> atanh2(1) = inf -> NaN next pass)
+    double lp[V];
 #pragma unroll
     for (int v = 0; v < V; v++) lp[v] = 0;
     for (int k = 0; k < dc; k++) {
@@ -289,7 +308,7 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
       for (int v = 0; v < V; v++) {
         const acc xv = (acc)x[v];
         const bool neg = xv < 0;
-        lp[v] = lp[v] + spa_logtanh2(neg ? -xv : xv);
+        lp[v] = lp[v] + (double)spa_logtanh2(neg ? -xv : xv);
         sg ^= (neg ? 1u : 0u) << v;
       }
     }
@@ -300,7 +319,7 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
       for (int v = 0; v < V; v++) {
         const acc xv = (acc)x[v];
         const bool neg = xv < 0;
-        const acc tout = spa_atanh2exp(lp[v] - spa_logtanh2(neg ? -xv : xv));
+        const acc tout = spa_atanh2exp((acc)(lp[v] - (double)spa_logtanh2(neg ? -xv : xv)));
         const bool flip = (((sg >> v) & 1u) != 0) != neg;
         o[v] = (T)(flip ? -tout : tout);
       }
@@ -528,7 +547,7 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
       // differences as the two-sweep kernels, half the transcendentals, one read of the rows
       static_assert(RB * V <= 64, "sign mask");
       unsigned long long negm = 0;
-      acc lp[V];
+      double lp[V];              // (binary64 sum: see cn_compute)
 #pragma unroll
       for (int v = 0; v < V; v++) lp[v] = 0;
 #pragma unroll
@@ -539,7 +558,7 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
             const acc xv = (acc)x[k][v];
             const bool neg = xv < 0;
             const acc l = spa_logtanh2(neg ? -xv : xv);
-            lp[v] = lp[v] + l;
+            lp[v] = lp[v] + (double)l;
             x[k][v] = (T)l;
             negm |= (unsigned long long)(neg ? 1u : 0u) << (k * V + v);
             sg ^= (neg ? 1u : 0u) << v;
@@ -551,7 +570,7 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
           vec o;
 #pragma unroll
           for (int v = 0; v < V; v++) {
-            const acc tout = spa_atanh2exp(lp[v] - (acc)x[k][v]);
+            const acc tout = spa_atanh2exp((acc)(lp[v] - (double)x[k][v]));
             const bool neg = ((negm >> (k * V + v)) & 1ull) != 0;
             const bool flip = (((sg >> v) & 1u) != 0) != neg;
             o[v] = (T)(flip ? -tout : tout);

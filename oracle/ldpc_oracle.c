@@ -352,8 +352,23 @@ int ora_dec_spa(const ora_code *c, const double *q0, const int *s, int loop_max,
   return rc;
 }
 
-static float atanh2f(float x) { return logf((1.0f + x) / (1.0f - x)); }
-static float logtanh2f(float x) { return logf(tanhf(fabsf(x * 0.5f))); }
+/* binary32 twin of logtanh2 / atanh2(exp(.)) (test_code_B_float.c:20-27).  Not in the reference
+ * (it computes in double).  The literal binary32 statement saturates at |LLR| ~ 17 (tanhf -> 1,
+ * then atanh2(1) = inf and inf - inf = NaN), where the reference's double still decodes; the
+ * twin therefore evaluates the same two functions without that cancellation (series of
+ * -2 atanh(e^-a) above 3, of -expm1(x) above -0.1 and of 2 atanh(e^x) below -3), as the
+ * binary32 kernels do (ldpc_amd/csrc/binary_kernels.hip.h).  0, -inf, NaN behave as before. */
+static float logtanh2f(float x) {
+  float a = fabsf(x);
+  if (a > 3.0f) { float t = expf(-a), t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
+  return logf(tanhf(a * 0.5f));
+}
+static float atanh2expf(float x) {
+  float e = expf(x);
+  if (x < -3.0f) { const float e2 = e * e; return 2.0f * e * (1.0f + e2 * (1.0f / 3.0f + e2 * 0.2f)); }
+  if (x > -0.1f) return logf((1.0f + e) / (fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
+  return logf((1.0f + e) / (1.0f - e));
+}
 
 int ora_dec_spa_f32(const ora_code *c, const float *q0, const int *s, int loop_max,
                     int *bits, int *synd, int *iters, float *post)
@@ -377,10 +392,10 @@ int ora_dec_spa_f32(const ora_code *c, const float *q0, const int *s, int loop_m
     }
     for (j = 0; j < m; j++) {
       int sgnprod = s[j];
-      float logprod = 0;
+      double logprod = 0;   /* binary64 sum, like the reference and the binary32 kernels */
       for (k = 0; k < c->row_weight[j]; k++) { logprod += MAG(j, k); sgnprod ^= SGN(j, k); }
       for (k = 0; k < c->row_weight[j]; k++) {
-        float tout = atanh2f(expf(logprod - MAG(j, k)));
+        float tout = atanh2expf((float)(logprod - (double)MAG(j, k)));
         int v = c->row_col[j * c->rmax + k], slot = c->row_N[j * c->rmax + k];
         if (sgnprod != SGN(j, k)) QIN(v, slot) = -tout;
         else QIN(v, slot) = tout;

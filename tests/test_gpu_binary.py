@@ -306,3 +306,35 @@ def test_spa_register_kernel_equals_two_sweep_kernels(hip, oracle, tmp_path, nam
     for o in outs[1:]:
         for k in want:
             assert np.array_equal(o[k], outs[0][k], equal_nan=True) if k == "llr" else np.array_equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("name,F,sigma,it", [("dvb_H_0.5.txt", 5, 0.84, 50), ("Frolov_1024_0.5.txt", 60, 0.62, 30),
+                                             ("204.33.484.txt", 200, 0.55, 30)])
+def test_spa_f32_follows_the_double_reference_past_binary32_saturation(hip, oracle, tmp_path, name, F, sigma, it):
+    """Messages beyond |LLR| ~ 17 (where tanhf rounds to 1): the literal binary32 statement of
+    logtanh2 / atanh2 turns them into inf and then NaN, the reference's double does not until
+    ~37.  SPA_F32's cancellation-free evaluation must keep deciding like the double reference
+    (oracle.dec_spa, test_code_B_float.c:134-199) on every frame whose double posteriors hold
+    no NaN: same verdict, same word when it converged, iteration count within 2 (binary32
+    rounding can move the last flip by an iteration), and no NaN of its own."""
+    path = code_path(name)
+    if name.startswith("dvb"):
+        path = str(tmp_path / "padded.alist")
+        hip.alist.normalise_alist(code_path(name), path, padded=True)
+    oc = oracle.load(path)
+    x, s, llr = make_frames(oracle, oc, F, 0.0, 41, "awgn", sigma=sigma)
+    ref = run_oracle(oracle.dec_spa, oc, llr, s, it)
+    code = hip.Code.from_alist(code_path(name))
+    dec = hip.Decoder(code, hip.ALG.SPA_F32, max_frames=256, want_llr=True)
+    out = dec.decode(llr.astype(np.float32), s.astype(np.uint8), it, want=("bits", "iters", "synd", "status", "llr"))
+    post = ref[4]
+    ok = ~np.isnan(post).any(axis=1)
+    assert ok.sum() >= 0.8 * F
+    assert np.abs(post[ok]).max() > 17.5, "case does not reach the binary32 saturation point"
+    assert not np.isnan(out["llr"][ok]).any()
+    assert np.array_equal(out["status"][ok], ref[3][ok])
+    conv = ok & (ref[3] == 0)
+    assert conv.sum() >= 0.5 * F
+    assert np.array_equal(out["bits"][conv], ref[0][conv])
+    assert (np.abs(out["iters"][conv] - ref[1][conv]) <= 2).all()
+    assert (out["iters"][conv] == ref[1][conv]).mean() > 0.9

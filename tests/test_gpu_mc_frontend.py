@@ -194,3 +194,30 @@ def test_msdp_entry_point(hip):
     assert err[0] >= 38
     assert L.test_code_B_MSDP(path, 5, 40, 1, 1, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == -6
     assert L.test_code_B_MSDP(path, 5, 40, 2, 0, conf.ctypes.data_as(C.POINTER(C.c_double)), dp) == -4
+
+
+def test_sweep_driver_on_the_device(hip, tmp_path):
+    """ldpc_amd.sweep (the loop of test_mex_B_float.m:20-36 around the harness): every point
+    equals a direct ldpc_mc_run on that point's seed, chunking does not change the frames,
+    the FER falls with the channel parameter, and a restart skips finished points."""
+    from ldpc_amd.sweep import ebn0_to_sigma, load_points, point_seed, sweep
+    code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88)
+    ps = [0.07, 0.05, 0.03]
+    out = str(tmp_path / "s.jsonl")
+    recs = sweep(mc, ps, 600, ref.BSC_EXACT, ref.I16, 30, seed=4, out_path=out)
+    for i, r in enumerate(recs):
+        direct = mc.run(600, ref.BSC_EXACT, ps[i], ref.I16, 30, seed=point_seed(4, i))
+        assert r["counters"] == direct and r["frames"] == 600
+        assert r["failures"] == direct["not_converged"] and r["undetected"] == direct["undetected"]
+    assert recs[0]["fer"] > recs[1]["fer"] > recs[2]["fer"] and recs[0]["fer"] > 0.2
+    chunked = sweep(mc, ps, 600, ref.BSC_EXACT, ref.I16, 30, seed=4, min_failures=10 ** 9, chunk=170)
+    assert [c["counters"] for c in chunked] == [r["counters"] for r in recs]
+    again = sweep(mc, ps, 600, ref.BSC_EXACT, ref.I16, 30, seed=4, out_path=out)
+    assert sorted(load_points(out)) == [0, 1, 2] and len(open(out).read().splitlines()) == 3
+    assert [a["counters"] for a in again] == [r["counters"] for r in recs]
+    # AWGN in Eb/N0: config[0]'s operating point (2 dB, 50 iterations, rate 1/2)
+    sg = ebn0_to_sigma(2.0, 0.5)
+    assert abs(sg - (1.0 / (2 * 0.5 * 10 ** 0.2)) ** 0.5) < 1e-15
+    code2, dec2, mc2 = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_F32)
+    aw = sweep(mc2, [1.0, 3.0], 2000, ref.AWGN, ref.F32, 50, seed=6, mc_params=[ebn0_to_sigma(1.0, 0.5), ebn0_to_sigma(3.0, 0.5)])
+    assert aw[0]["fer"] > aw[1]["fer"] and aw[0]["avg_iterations"] > aw[1]["avg_iterations"]

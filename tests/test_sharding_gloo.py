@@ -103,3 +103,61 @@ def test_run_sharded_two_ranks_equals_one(tmp_path):
     one = _FakeMonteCarlo().run(total, 0, 0.1, 2, 10, seed=5)
     assert np.load(out).tolist() == [one[k] for k in ("frames", "not_converged", "undetected", "bit_errors")]
     assert one["frames"] == total and 0 < one["not_converged"] < total
+
+
+def _sweep_worker(rank, world, port, out, frames, min_failures):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ldpc_amd.sweep import sweep
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sweep(_FakeMonteCarlo(), [0.1, 0.2, 0.3], frames, 0, 2, 10, seed=9, out_path=out, min_failures=min_failures,
+          chunk=50)
+    dist.destroy_process_group()
+
+
+def test_sweep_two_ranks_equals_one_and_resumes(tmp_path):
+    """The sweep driver (test_mex_B_float.m:20-36 / parallel.py:385-396 semantics): per-point
+    counters do not depend on the world size or on chunking; the JSON-lines checkpoint lets a
+    restart skip finished points (the reference's save('full_env.mat') per point)."""
+    import json
+    from ldpc_amd.sweep import load_points, sweep
+    two = str(tmp_path / "two.jsonl")
+    mp.spawn(_sweep_worker, args=(2, _free_port(), two, 230, None), nprocs=2, join=True)
+    one = sweep(_FakeMonteCarlo(), [0.1, 0.2, 0.3], 230, 0, 2, 10, seed=9)
+    got = load_points(two)
+    assert sorted(got) == [0, 1, 2]
+    for r in one:
+        g = got[r["index"]]
+        assert g["world"] == 2 and r["world"] == 1
+        assert g["counters"] == r["counters"] and g["frames"] == 230
+        assert g["fer"] == r["fer"] == r["failures"] / 230
+    # different points draw different frames
+    assert one[0]["counters"] != one[1]["counters"] or one[1]["counters"] != one[2]["counters"]
+    # resume: drop the last record (and leave a line cut off mid-write); only that point is re-run
+    lines = open(two).read().splitlines()
+    part = str(tmp_path / "part.jsonl")
+    with open(part, "w") as f:
+        f.write("\n".join(lines[:2]) + "\n" + lines[2][:40])
+
+    class Counting(_FakeMonteCarlo):
+        calls = 0
+
+        def run(self, *a, **k):
+            Counting.calls += 1
+            return super().run(*a, **k)
+    with open(part, "a") as f:
+        f.write("\n")
+    recs = sweep(Counting(), [0.1, 0.2, 0.3], 230, 0, 2, 10, seed=9, out_path=part)
+    assert Counting.calls == 1 and recs[2]["counters"] == one[2]["counters"]
+    assert [json.loads(l)["index"] for l in open(part).read().splitlines() if l.startswith('{"index"') and l.endswith("}")] == [0, 1, 2]
+    # early stop: chunks of 50 frames until >= 12 failures, same stop on 1 and 2 ranks
+    stop2 = str(tmp_path / "stop2.jsonl")
+    mp.spawn(_sweep_worker, args=(2, _free_port(), stop2, 1000, 12), nprocs=2, join=True)
+    stop1 = sweep(_FakeMonteCarlo(), [0.1, 0.2, 0.3], 1000, 0, 2, 10, seed=9, min_failures=12, chunk=50)
+    g2 = load_points(stop2)
+    for r in stop1:
+        assert r["frames"] % 50 == 0 and r["failures"] + r["undetected"] >= 12 or r["frames"] == 1000
+        assert g2[r["index"]]["counters"] == r["counters"]
+    assert any(r["frames"] < 1000 for r in stop1)
