@@ -359,9 +359,12 @@ int ora_dec_spa(const ora_code *c, const double *q0, const int *s, int loop_max,
  * -2 atanh(e^-a) above 3, of -expm1(x) above -0.1 and of 2 atanh(e^x) below -3), as the
  * binary32 kernels do (ldpc_amd/csrc/binary_kernels.hip.h).  0, -inf, NaN behave as before. */
 static float logtanh2f(float x) {
-  float a = fabsf(x);
-  if (a > 3.0f) { float t = expf(-a), t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
-  return logf(tanhf(a * 0.5f));
+  float a = fabsf(x), t = expf(-a), num;
+  if (a > 3.0f) { float t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
+  num = 1.0f - t;
+  if (a < 0.25f)
+    num = a * (1.0f - a * (0.5f - a * (1.0f / 6.0f - a * (1.0f / 24.0f - a * (1.0f / 120.0f - a * (1.0f / 720.0f))))));
+  return logf(num / (1.0f + t));
 }
 static float atanh2expf(float x) {
   float e = expf(x);
