@@ -85,7 +85,9 @@ typedef enum ldpc_alg {
   LDPC_ALG_MINSUM_F32    = 0, /* dec(), test_code_min_sum_B.c:137-208, binary32 messages       */
   LDPC_ALG_MINSUM_F64    = 1, /* same in binary64: the reference's own arithmetic, bit-exact   */
   LDPC_ALG_MINSUM_Q88    = 2, /* dec(), test_code_min_sum_B_fixed.c:192-316, int16 Q8.8        */
-  LDPC_ALG_SPA_F32       = 3, /* dec(), test_code_B_float.c:134-199, binary32                  */
+  LDPC_ALG_SPA_F32       = 3, /* dec(), test_code_B_float.c:134-199, binary32 messages: logtanh2 /
+                                 atanh2 evaluated without cancellation, logprod summed in binary64,
+                                 so that it follows the reference's double past |LLR| ~ 17        */
   LDPC_ALG_SPA_F64       = 4, /* same in binary64                                              */
   LDPC_ALG_SPA_TABLE_Q14 = 5, /* dec(), test_code_B.c:171-233 / test_code_no_mex_B.c:170-242   */
   LDPC_ALG_GF2P_WHT      = 6, /* dec(), GFq_LDPC_NTT.c:437-544, GF(2^p) integer WHT domain     */
