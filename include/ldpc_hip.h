@@ -306,6 +306,20 @@ int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, i
 int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
              int num_reads, int decode_mode, double *p_rec_given_sent, double *errors);
 
+/* GFq_LDPC() of WD_farm/GFq_LDPC.c:477 (mex gateway :635-709): same harness, but the graph is
+ * passed in as the flat arrays WD_farm/InitSumProductDecoderSyndrome.m builds, row-major and
+ * 0-based as that function indexes them (:310, :370): row_list_col[nchk][rmax], H[nchk][rmax]
+ * (coefficients 1..q-1), col_list_row / col_list_N[nvar][cmax] (row and position-in-row of each
+ * variable's k-th edge), col_weight[nvar], row_weight[nchk].  The column-side arrays are
+ * redundant with the rows; they are checked against them (NULL = not checked).  q replaces the
+ * reference's compile-time `#define Q`.  A distinct symbol: the reference reuses the name
+ * GFq_LDPC for both arities. */
+int GFq_LDPC_graph(int q, int iteration, int num_trials, int num_strs_seek, int num_reads,
+                   int decode_mode, double *p_rec_given_sent, int nvar, int nchk, int cmax_in,
+                   int rmax_in, const int *col_weight_in, const int *row_weight_in,
+                   const int *row_list_col_in, const int *col_list_row_in, const int *col_list_N_in,
+                   const int *H_in, double *errors);
+
 /* main() of GFq_LDPC_NTT.c:641-703, the GF(2^p) Walsh-Hadamard program
  *   GFq_LDPC_NTT [-iter num] <lap|bsc> NoiseLevel ParityMatrix        (:656-663)
  * as a function: three experiments, SRand(j) for j = 1..3 (:681-695), each

@@ -305,10 +305,10 @@ extern "C" int test_code_B_MSDP(const char *code_filename, int iteration, int nu
   return LDPC_OK;
 }
 
-// GFq_LDPC(), GFq_LDPC.c:540-655
-extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
-                        int num_reads, int decode_mode, double *p_rec_given_sent, double *errors) {
-  (void)num_strs_seek;   // only used by a commented-out fseek in the reference (:587)
+// The trial loop of GFq_LDPC(), GFq_LDPC.c:540-655 (same in WD_farm/GFq_LDPC.c:477-633), on a
+// given graph and decoder.
+static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num_trials, int num_reads,
+                      int decode_mode, double *p_rec_given_sent, double *errors) {
   if (!errors) return LDPC_ERR_ARG;
   errors[0] = errors[1] = 0;
   if (!p_rec_given_sent || num_reads <= 0 || num_trials < 0 || iteration < 0) return LDPC_ERR_ARG;
@@ -318,10 +318,7 @@ extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials
     ldpc_set_error("GFq_LDPC: decode_mode 1 (page files) is not supported");
     return LDPC_ERR_UNSUPPORTED;
   }
-  ldpc_code *code;
-  ldpc_decoder *dec;
-  int rc = get_decoder(code_filename, LDPC_ALG_GFQ_DIRECT, &code, &dec);
-  if (rc) return rc;
+  int rc;
   HostGraph g(code);
   const int Q = g.q, n = g.n, m = g.m, R = Q * num_reads;
 
@@ -383,6 +380,83 @@ extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials
     }
   }
   return LDPC_OK;
+}
+
+// GFq_LDPC(), GFq_LDPC.c:540-655
+extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
+                        int num_reads, int decode_mode, double *p_rec_given_sent, double *errors) {
+  (void)num_strs_seek;   // only used by a commented-out fseek in the reference (:587)
+  if (errors) errors[0] = errors[1] = 0;
+  ldpc_code *code;
+  ldpc_decoder *dec;
+  int rc = get_decoder(code_filename, LDPC_ALG_GFQ_DIRECT, &code, &dec);
+  if (rc) return rc;
+  return gfq_trials(code, dec, iteration, num_trials, num_reads, decode_mode, p_rec_given_sent, errors);
+}
+
+// GFq_LDPC() of WD_farm/GFq_LDPC.c:477: the graph comes in as the flat arrays that
+// InitSumProductDecoderSyndrome.m builds instead of a file name.
+extern "C" int GFq_LDPC_graph(int q, int iteration, int num_trials, int num_strs_seek, int num_reads,
+                              int decode_mode, double *p_rec_given_sent, int nvar, int nchk, int cmax_in,
+                              int rmax_in, const int *col_weight_in, const int *row_weight_in,
+                              const int *row_list_col_in, const int *col_list_row_in, const int *col_list_N_in,
+                              const int *H_in, double *errors) {
+  (void)num_strs_seek;
+  if (errors) errors[0] = errors[1] = 0;
+  if (q < 2 || nvar <= 0 || nchk <= 0 || cmax_in <= 0 || rmax_in <= 0 || !row_weight_in || !row_list_col_in || !H_in)
+    return LDPC_ERR_ARG;
+  std::vector<int32_t> row_ptr((size_t)nchk + 1, 0), col_idx, hval, colw((size_t)nvar, 0);
+  for (int j = 0; j < nchk; j++) {
+    const int w = row_weight_in[j];
+    if (w < 0 || w > rmax_in) {
+      ldpc_set_error("GFq_LDPC_graph: row_weight[" + std::to_string(j) + "] = " + std::to_string(w) + " outside 0..rmax");
+      return LDPC_ERR_ARG;
+    }
+    row_ptr[j + 1] = row_ptr[j] + w;
+    for (int k = 0; k < w; k++) {
+      const int v = row_list_col_in[(size_t)j * rmax_in + k], h = H_in[(size_t)j * rmax_in + k];
+      if (v < 0 || v >= nvar || h <= 0 || h >= q) {
+        ldpc_set_error("GFq_LDPC_graph: row " + std::to_string(j) + " entry " + std::to_string(k) + ": column " + std::to_string(v) + " / value " + std::to_string(h) + " out of range");
+        return LDPC_ERR_ARG;
+      }
+      // the view from the variable's side must be the one the rows imply (slot = order of
+      // appearance over ascending rows, InitSumProductDecoderSyndrome.m / GFq_LDPC.c:505-515)
+      if (col_list_row_in && col_list_N_in) {
+        const int slot = colw[v];
+        if (slot >= cmax_in || col_list_row_in[(size_t)v * cmax_in + slot] != j ||
+            col_list_N_in[(size_t)v * cmax_in + slot] != k) {
+          ldpc_set_error("GFq_LDPC_graph: col_list_row / col_list_N disagree with the rows at variable " + std::to_string(v) + " slot " + std::to_string(slot));
+          return LDPC_ERR_ARG;
+        }
+      }
+      colw[v]++;
+      col_idx.push_back(v);
+      hval.push_back(h);
+    }
+  }
+  if (col_weight_in)
+    for (int v = 0; v < nvar; v++)
+      if (col_weight_in[v] != colw[v]) {
+        ldpc_set_error("GFq_LDPC_graph: col_weight[" + std::to_string(v) + "] = " + std::to_string(col_weight_in[v]) + " but the rows hold it " + std::to_string(colw[v]) + " times");
+        return LDPC_ERR_ARG;
+      }
+  ldpc_code *code = nullptr;
+  int rc = ldpc_code_from_csr(nvar, nchk, q, row_ptr.data(), col_idx.data(), hval.data(), &code);
+  if (rc) return rc;
+  ldpc_opts o;
+  memset(&o, 0, sizeof o);
+  o.alg = LDPC_ALG_GFQ_DIRECT;
+  o.device = cache_device();
+  o.max_frames = mc_batch();
+  o.early_exit = 1;
+  ldpc_decoder *dec = nullptr;
+  rc = ldpc_decoder_create(code, &o, &dec);
+  if (!rc) {
+    rc = gfq_trials(code, dec, iteration, num_trials, num_reads, decode_mode, p_rec_given_sent, errors);
+    ldpc_decoder_free(dec);
+  }
+  ldpc_code_free(code);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -110,6 +110,7 @@ def load_library():
     L.test_code_B_float_cw_noise_gen.argtypes = [cp, ip, ip, C.c_double, dp]
     L.test_code_B.argtypes = [ip, ip, C.c_double, cp, dp]
     L.GFq_LDPC.argtypes = [cp, ip, ip, ip, ip, ip, dp, dp]
+    L.GFq_LDPC_graph.argtypes = [ip, ip, ip, ip, ip, ip, dp, ip, ip, ip, ip, intp, intp, intp, intp, intp, intp, dp]
     L.test_code_B_MSDP.argtypes = [cp, ip, ip, ip, ip, dp, dp]
     L.GFq_LDPC_NTT.argtypes = [ip, cp, C.c_double, cp, vp, vp]
     L.GFq_LDPC_NTT_experiment.argtypes = [cp, ip, cp, C.c_double, vp, vp, vp, vp]

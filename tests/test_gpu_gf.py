@@ -169,3 +169,53 @@ def test_GFq_LDPC_NTT_program(hip, q, fname, channel, level):
     rc = L.GFq_LDPC_NTT(1, channel.encode(), level, code_path(fname).encode(), verdict.ctypes.data, None)
     assert rc == 0 and (verdict == -1).all()
     assert L.GFq_LDPC_NTT(5, b"awgn", level, code_path(fname).encode(), verdict.ctypes.data, None) < 0
+
+
+def test_gfq_ldpc_graph_passing_boundary(hip):
+    """GFq_LDPC() of WD_farm/GFq_LDPC.c:477: the graph handed over as the flat arrays of
+    InitSumProductDecoderSyndrome.m instead of a file.  Same seed -> same trials -> the same
+    [failures, undetected] as the file-name entry point; inconsistent arrays are refused."""
+    import ctypes as C
+    L = hip.load_library()
+    path = code_path("peg_4376_4_0.9_NB.txt")
+    code = hip.Code.from_alist(path)
+    rp, ci, hv = code.csr()
+    n, m, q = code.n, code.m, code.q
+    rw = np.diff(rp).astype(np.int32)
+    rmax = int(rw.max())
+    rlc = np.zeros((m, rmax), np.int32)
+    H = np.zeros((m, rmax), np.int32)
+    cw = np.zeros(n, np.int32)
+    cmax = int(np.bincount(ci, minlength=n).max())
+    clr = np.zeros((n, cmax), np.int32)
+    clN = np.zeros((n, cmax), np.int32)
+    for j in range(m):
+        for k in range(rw[j]):
+            v = ci[rp[j] + k]
+            rlc[j, k], H[j, k] = v, hv[rp[j] + k]
+            clr[v, cw[v]], clN[v, cw[v]] = j, k
+            cw[v] += 1
+    ip = C.POINTER(C.c_int)
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(ip)
+    res = []
+    for p_sym, iters, trials in ((0.01, 15, 5), (0.5, 3, 3)):
+        conf = np.ascontiguousarray(_conf_matrix(q, p_sym))
+        e1, e2 = (C.c_double * 2)(), (C.c_double * 2)()
+        L.ldpc_set_seed(99)
+        assert L.GFq_LDPC(path.encode(), iters, trials, 0, 1, 0, conf.copy().ctypes.data_as(dp), e1) == 0
+        L.ldpc_set_seed(99)
+        c2 = conf.copy()
+        rc = L.GFq_LDPC_graph(q, iters, trials, 0, 1, 0, c2.ctypes.data_as(dp), n, m, cmax, rmax, P(cw), P(rw), P(rlc),
+                              P(clr), P(clN), P(H), e2)
+        assert rc == 0, L.ldpc_last_error()
+        assert list(e1) == list(e2)
+        res.append(list(e2))
+    assert res[0] == [0.0, 0.0] and res[1][0] == 3.0
+    bad = clN.copy()
+    bad[7, 0] += 1
+    e = (C.c_double * 2)()
+    conf = np.ascontiguousarray(_conf_matrix(q, 0.01))
+    assert L.GFq_LDPC_graph(q, 3, 1, 0, 1, 0, conf.ctypes.data_as(dp), n, m, cmax, rmax, P(cw), P(rw), P(rlc), P(clr),
+                            P(bad), P(H), e) < 0
+    assert b"col_list" in L.ldpc_last_error()
