@@ -49,6 +49,12 @@ def main():
                 llr = torch.where(flips, -int(L * 16384 + 0.5), int(L * 16384 + 0.5)).to(tdt)
             else:
                 llr = torch.where(flips, -L, L).to(tdt)
+                if os.environ.get("BENCH_CODES_LLR", "bsc") == "awgn":
+                    # continuous magnitudes (BPSK + Gaussian noise at a hopeless SNR, so that every frame
+                    # still runs all iterations): lanes of a wavefront then differ in the value-dependent
+                    # branches of the sum-product functions, which equal-magnitude BSC inputs never show
+                    sg = 1.6
+                    llr = ((1.0 + sg * torch.randn((F, n), device=dev, generator=gen)) * (2.0 / sg ** 2)).to(tdt)
             llr = llr.contiguous()
             bits = torch.empty((F, n), dtype=torch.uint8, device=dev)
             status = torch.empty(F, dtype=torch.int32, device=dev)
