@@ -135,6 +135,9 @@ def test_sweep_two_ranks_equals_one_and_resumes(tmp_path):
         assert g["fer"] == r["fer"] == r["failures"] / 230
     # different points draw different frames
     assert one[0]["counters"] != one[1]["counters"] or one[1]["counters"] != one[2]["counters"]
+    # a second two-rank run on the finished file runs nothing (rank 0 reads it, every rank skips alike)
+    mp.spawn(_sweep_worker, args=(2, _free_port(), two, 230, None), nprocs=2, join=True)
+    assert len(open(two).read().splitlines()) == 3
     # resume: drop the last record (and leave a line cut off mid-write); only that point is re-run
     lines = open(two).read().splitlines()
     part = str(tmp_path / "part.jsonl")
