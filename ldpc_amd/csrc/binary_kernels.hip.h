@@ -235,20 +235,26 @@ template <typename A> struct CnStateMin {
 // 2 atanh(e^x) with 1 - e^x from the series of -expm1(x) above -0.1 and the atanh series
 // below -3.  Worst relative error against exact arithmetic 9e-7 (binary32 rounding).  Values at 0, -inf and NaN stay the
 // reference's.
+// v_exp_f32 / v_log_f32 / v_rcp_f32 directly (1 ulp): __expf / __logf wrap them in denormal
+// range handling and __fdividef compiles to the IEEE division sequence (measured: 96 v_div_fmas
+// and 400 compares in the register kernel).  The arguments here never need either: log of a
+// ratio in (1e-37, 2e7], exp of a non-positive number whose underflow to 0 is the right answer.
+__device__ __forceinline__ float spa_fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float spa_flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 __device__ __forceinline__ float spa_logtanh2(float a) {
-  const float t = __expf(-a);             // tanh(a/2) = (1 - t) / (1 + t): one exp, no tanhf
+  const float t = spa_fexp(-a);             // tanh(a/2) = (1 - t) / (1 + t): one exp, no tanhf
   if (a > 3.0f) { const float t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
   float num = 1.0f - t;
   if (a < 0.25f)                        // 1 - e^-a by its series where the difference cancels
     num = a * (1.0f - a * (0.5f - a * (1.0f / 6.0f - a * (1.0f / 24.0f - a * (1.0f / 120.0f - a * (1.0f / 720.0f))))));
-  return __logf(__fdividef(num, 1.0f + t));
+  return spa_flog(num * __builtin_amdgcn_rcpf(1.0f + t));
 }
 __device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
 __device__ __forceinline__ float spa_atanh2exp(float x) {
-  const float e = __expf(x);
+  const float e = spa_fexp(x);
   if (x < -3.0f) { const float e2 = e * e; return 2.0f * e * (1.0f + e2 * (1.0f / 3.0f + e2 * 0.2f)); }
-  if (x > -0.1f) return __logf(__fdividef(1.0f + e, fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
-  return __logf(__fdividef(1.0f + e, 1.0f - e));
+  if (x > -0.1f) return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
+  return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(1.0f - e));
 }
 __device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
 
