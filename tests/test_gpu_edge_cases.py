@@ -100,3 +100,26 @@ def test_bad_arguments_are_refused_and_the_decoder_survives(hip, oracle):
         hip.Code.from_alist(code_path("no_such_file.txt"))    # exit(-2) in the reference (:216-219)
     with pytest.raises(hip.LdpcError):
         hip.Decoder(code, 99)                                 # unknown algorithm
+
+
+def test_gf_no_frames_and_zero_iterations(hip, oracle):
+    """Same edges on the GF(4) Walsh-Hadamard decoder, inputs = the committed vectors of the
+    compiled reference program (tests/golden/ref_ntt_q4.npz)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ref_ntt_q4.npz"))
+    fname = "q4.sp.9000.6000.4500.1"
+    code = hip.Code.from_alist(code_path(fname))
+    oc = oracle.load(code_path(fname))
+    dec = hip.Decoder(code, hip.ALG.GF2P_WHT, max_frames=2)            # 4 frames: two passes
+    lf, s = g["logfna"].astype(np.int32), g["s"]
+    out = dec.decode(lf[:0], s[:0], 5)
+    assert out["bits"].shape == (0, code.n) and out["status"].shape == (0,)
+    out = dec.decode(lf, s, 0)
+    ref = [oracle.dec_gf2p_wht(oc, 2, lf[f], s[f].astype(np.int32), 0) for f in range(len(lf))]
+    assert np.array_equal(out["bits"], np.stack([r["x"] for r in ref]))
+    assert np.array_equal(out["synd"], np.stack([r["z"] for r in ref]))
+    assert np.array_equal(out["status"] != 0, np.array([r["rc"] != 0 for r in ref]))
+    assert np.array_equal(out["iters"], np.array([r["iters"] for r in ref]))
+    full = dec.decode(lf, s, int(g["maxit"]))
+    assert np.array_equal(full["bits"], g["xhat"]) and np.array_equal(full["status"] != 0, g["rc"] != 0)
