@@ -158,6 +158,26 @@ int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void *llr, int 
                              uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
                              int32_t *status_out, float *llr_out, void *stream);
 
+/* ldpc_decode_batch_device() for callers that cannot allocate device memory -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
+ * counterpart in the reference (whose dec() works in file-scope host arrays).  Same arguments,
+ * same results; but every byte of device scratch the call needs -- the frame-queue head of
+ * the frame-resident decoders; the edge-message store, hard decisions and per-frame state of
+ * the two-pass decoders -- comes from one file-scope `static __device__` array of
+ * 32 MiB that each GPU the library runs on holds until the process ends (its per-device
+ * address is resolved once, in ldpc_decoder_create()).  The call makes no hipMalloc /
+ * hipFree / allocating library call.  Binary algorithms only.  Limits, refused with
+ * LDPC_ERR_ARG and a message naming the figure: the two-pass decoders need
+ * 64 * ceil(nframes / SF) * (16 n + 16 E + n + 2 m + ...) bytes (SF = 512 frames for int16
+ * messages, 256 for binary32 / int32, 128 for binary64), which must fit the 32 MiB; their
+ * max_iter is at most 254; per-kernel timing (ldpc_decoder_profile) is off inside the call.
+ * All calls on one GPU share that GPU's array: the call clears what must start at zero, and
+ * two calls that overlap on one GPU (two decoders, two streams, two host threads) race. */
+int ldpc_decode_batch_device_noalloc(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                                     const uint8_t *syndrome, int max_iter,
+                                     uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
+                                     int32_t *status_out, float *llr_out, void *stream);
+
 /* Single-frame MINSUM_Q88 decode that also writes the Verilog message trace
  * of test_code_min_sum_B_fixed.c (:205 "already cw", :245-260 the v2c dump,
  * :288-296 the c2v dump; one "%08x" line per message per iteration) to

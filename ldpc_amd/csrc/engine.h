@@ -43,6 +43,9 @@ inline bool ldpc_sync_launches() {
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   int ensure(size_t want) {
     if (want <= bytes) return LDPC_OK;
@@ -60,6 +63,18 @@ struct DevBuf {
   template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
 };
 
+// Points a DevBuf at caller-provided device memory for the life of the guard (the
+// allocation-free entry point carves an engine's workspace out of one array this way).
+struct DevBufBorrow {
+  DevBuf &b;
+  void *p0;
+  size_t n0;
+  DevBufBorrow(DevBuf &buf, void *p, size_t n) : b(buf), p0(buf.p), n0(buf.bytes) { b.p = p; b.bytes = n; }
+  ~DevBufBorrow() { b.p = p0; b.bytes = n0; }
+  DevBufBorrow(const DevBufBorrow &) = delete;
+  DevBufBorrow &operator=(const DevBufBorrow &) = delete;
+};
+
 struct Engine {
   virtual ~Engine() { profile_free(); }
   virtual int init(const ldpc_code &c, const ldpc_opts &o) = 0;
@@ -72,6 +87,14 @@ struct Engine {
   virtual int decode_traced(const void *, int, const uint8_t *, int, uint8_t *, int32_t *, uint8_t *,
                             int32_t *, FILE *, int) {
     ldpc_set_error("message trace is only available for MINSUM_Q88");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  // decode() with every byte of device scratch the call needs (work-queue head, message
+  // store, per-frame state) taken from ws[0 .. ws_bytes) instead of the engine's own
+  // buffers; allocates nothing.  ws is 256-byte aligned device memory.
+  virtual int decode_ws(void *, size_t, int, const void *, int, const uint8_t *, int, uint8_t *, int32_t *,
+                        uint8_t *, int32_t *, float *, hipStream_t) {
+    ldpc_set_error("the allocation-free entry point serves the binary decoders only");
     return LDPC_ERR_UNSUPPORTED;
   }
   int last_iterations = 0;

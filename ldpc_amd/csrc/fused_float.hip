@@ -761,7 +761,8 @@ struct FusedFloatEngine : Engine {
       ldpc_set_error("llr_out needs opts.want_llr");
       return LDPC_ERR_ARG;
     }
-    HIPCHK(hipMemsetAsync(d_counter.p, 0, 4, st));
+    int *counter = ws_counter ? ws_counter : d_counter.as<int>();
+    HIPCHK(hipMemsetAsync(counter, 0, 4, st));
     FfArgs a;
     a.colT = d_colT.as<uint16_t>();
     a.realT = d_realT.as<uint32_t>();
@@ -772,7 +773,7 @@ struct FusedFloatEngine : Engine {
     a.nframes = nframes; a.max_iter = max_iter;
     a.llr = llr; a.dt = dt; a.synd = sy;
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
-    a.counter = d_counter.as<int>();
+    a.counter = counter;
     a.vtabT = d_vtabT.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
@@ -783,6 +784,18 @@ struct FusedFloatEngine : Engine {
     prof_end(st);
     last_iterations = max_iter;
     return LDPC_OK;
+  }
+
+  // the kernel's only device scratch is the frame queue head: one word of ws
+  int *ws_counter = nullptr;
+  int decode_ws(void *ws, size_t ws_bytes, int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter,
+                uint8_t *bits, int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out,
+                hipStream_t st) override {
+    if (!ws || ws_bytes < 256) { ldpc_set_error("scratch too small for the frame queue head"); return LDPC_ERR_ARG; }
+    ws_counter = (int *)ws;
+    const int rc = decode(nframes, llr, dt, sy, max_iter, bits, iters_out, sout, status, llr_out, st);
+    ws_counter = nullptr;
+    return rc;
   }
 };
 

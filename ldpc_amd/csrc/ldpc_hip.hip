@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -436,6 +437,59 @@ struct BinaryEngine : Engine {
     return emit_outputs(nframes, nslab, max_iter, bits, iters_out, sout_out, status, llr_out, st);
   }
 
+  // Workspace of one decode call of nslab slabs, as (offset, bytes) into a 256-byte aligned
+  // array: q0, msg, post, hard, synd, sout, fail, done, iters, remaining -- the buffers init()
+  // allocates for nslab_max slabs.  Returns the total.
+  enum { WS_Q0, WS_MSG, WS_POST, WS_HARD, WS_SYND, WS_SOUT, WS_FAIL, WS_DONE, WS_ITERS, WS_REM, WS_N };
+  size_t ws_layout(int nslab, int rem_slots, size_t off[WS_N], size_t len[WS_N]) const {
+    const size_t rows = (size_t)nslab * 64;
+    len[WS_Q0] = rows * n * sizeof(vec);
+    len[WS_MSG] = rows * E * sizeof(vec);
+    len[WS_POST] = opts.want_llr ? rows * n * sizeof(vec) : 0;
+    len[WS_HARD] = rows * n;
+    len[WS_SYND] = rows * m;
+    len[WS_SOUT] = rows * m;
+    len[WS_FAIL] = rows * sizeof(uint32_t);
+    len[WS_DONE] = rows;
+    len[WS_ITERS] = rows * V * sizeof(int32_t);
+    len[WS_REM] = sizeof(int32_t) * (size_t)rem_slots;
+    size_t at = 0;
+    for (int i = 0; i < WS_N; i++) { off[i] = at; at += (len[i] + 255) & ~(size_t)255; }
+    return at;
+  }
+
+  int decode_ws(void *ws, size_t ws_bytes, int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter,
+                uint8_t *bits, int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+                hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
+    if (!ws || nframes > nslab_max * SF || max_iter < 0) {
+      ldpc_set_error("nframes/max_iter out of range for this decoder");
+      return LDPC_ERR_ARG;
+    }
+    // the host-side poll slots were pinned by init(); growing them would allocate
+    if (max_iter + 2 > remaining_cap) {
+      ldpc_set_error("allocation-free decode: max_iter " + std::to_string(max_iter) + " beyond the " +
+                     std::to_string(remaining_cap - 2) + " iterations this entry point serves");
+      return LDPC_ERR_ARG;
+    }
+    const int nslab = (nframes + SF - 1) / SF;
+    size_t off[WS_N], len[WS_N];
+    const size_t need = ws_layout(nslab, remaining_cap, off, len);
+    if (need > ws_bytes) {
+      ldpc_set_error("allocation-free decode: " + std::to_string(nframes) + " frames of this code need " +
+                     std::to_string(need) + " bytes of message store, the static scratch holds " +
+                     std::to_string(ws_bytes) + " (use ldpc_decode_batch_device, or fewer frames per call)");
+      return LDPC_ERR_ARG;
+    }
+    char *w = (char *)ws;
+    DevBufBorrow b0(q0, w + off[WS_Q0], len[WS_Q0]), b1(msg, w + off[WS_MSG], len[WS_MSG]),
+        b2(post, opts.want_llr ? w + off[WS_POST] : nullptr, len[WS_POST]), b3(hard, w + off[WS_HARD], len[WS_HARD]),
+        b4(synd, w + off[WS_SYND], len[WS_SYND]), b5(sout, w + off[WS_SOUT], len[WS_SOUT]),
+        b6(fail, w + off[WS_FAIL], len[WS_FAIL]), b7(done, w + off[WS_DONE], len[WS_DONE]),
+        b8(iters, w + off[WS_ITERS], len[WS_ITERS]), b9(remaining, w + off[WS_REM], len[WS_REM]);
+    return decode(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+  }
+
   int emit_outputs(int nframes, int nslab, int max_iter, uint8_t *bits, int32_t *iters_out,
                    uint8_t *sout_out, int32_t *status, float *llr_out, hipStream_t st) {
     if (bits) {
@@ -758,7 +812,8 @@ struct FusedQ88Engine : Engine {
       ldpc_set_error("bad arguments to the fused Q8.8 decoder");
       return LDPC_ERR_ARG;
     }
-    HIPCHK(hipMemsetAsync(d_counter.p, 0, 4, st));
+    int *counter = ws_counter ? ws_counter : d_counter.as<int>();
+    HIPCHK(hipMemsetAsync(counter, 0, 4, st));
     if (sout) HIPCHK(hipMemsetAsync(sout, 0, (size_t)nframes * m, st));
     FusedArgs a;
     a.colT = d_colT.as<uint16_t>();
@@ -767,7 +822,7 @@ struct FusedQ88Engine : Engine {
     a.nframes = nframes; a.max_iter = max_iter;
     a.llr = llr; a.dt = dt; a.synd = sy;
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
-    a.counter = d_counter.as<int>();
+    a.counter = counter;
     a.pos = d_pos.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
     a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
@@ -780,8 +835,48 @@ struct FusedQ88Engine : Engine {
     last_iterations = max_iter;
     return LDPC_OK;
   }
+
+  // the kernel's only device scratch is the frame queue head: one word of ws
+  int *ws_counter = nullptr;
+  int decode_ws(void *ws, size_t ws_bytes, int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter,
+                uint8_t *bits, int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out,
+                hipStream_t st) override {
+    if (!ws || ws_bytes < 256) { ldpc_set_error("scratch too small for the frame queue head"); return LDPC_ERR_ARG; }
+    ws_counter = (int *)ws;
+    const int rc = decode(nframes, llr, dt, sy, max_iter, bits, iters_out, sout, status, llr_out, st);
+    ws_counter = nullptr;
+    return rc;
+  }
 };
 
+}  // namespace
+
+// ------------------------------------------------ the allocation-free entry point
+// Device scratch of ldpc_decode_batch_device_noalloc(): a file-scope array instead of
+// hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy, at its own
+// address, until the process ends; `scratch` below is only the host-side stand-in for
+// hipGetSymbolAddress -- host code uses the per-device pointer it returns.
+#define LDPC_NOALLOC_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scratch[LDPC_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[MAX_DEVICES] = {};
+
+// Address of `scratch` on `device` (which must be the current device); resolved once per device.
+int scratch_on_device(int device, void **out) {
+  if (device < 0 || device >= MAX_DEVICES) { ldpc_set_error("device ordinal beyond the scratch table"); return LDPC_ERR_ARG; }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) { ldpc_set_error("hipGetSymbolAddress(scratch) returned null"); return LDPC_ERR_HIP; }
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return LDPC_OK;
+}
 }  // namespace
 
 // ---------------------------------------------------------------- decoder
@@ -808,6 +903,12 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
     return LDPC_ERR_ARG;
   }
   HIPCHK(hipSetDevice(opts->device));
+  {
+    // set-up of the allocation-free entry point: this device's address of the static scratch
+    void *ws = nullptr;
+    int rc = scratch_on_device(opts->device, &ws);
+    if (rc) return rc;
+  }
   std::unique_ptr<ldpc_decoder> d(new (std::nothrow) ldpc_decoder);
   if (!d) return LDPC_ERR_NOMEM;
   d->code = *c;
@@ -971,6 +1072,28 @@ extern "C" int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void
   HIPCHK(hipSetDevice(d->opts.device));
   return d->eng->decode(nframes, llr, llr_dtype, syndrome, max_iter, bits_out, iters_out, synd_out,
                         status_out, llr_out, (hipStream_t)stream);
+}
+
+extern "C" int ldpc_decode_batch_device_noalloc(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
+                                                const uint8_t *syndrome, int max_iter, uint8_t *bits_out,
+                                                int32_t *iters_out, uint8_t *synd_out, int32_t *status_out,
+                                                float *llr_out, void *stream) {
+  if (!d) return LDPC_ERR_ARG;
+  if (nframes > d->max_frames) {
+    ldpc_set_error("nframes exceeds the decoder's max_frames");
+    return LDPC_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(d->opts.device));
+  void *ws = nullptr;
+  int rc = scratch_on_device(d->opts.device, &ws);   // resolved by ldpc_decoder_create(); a lookup here
+  if (rc) return rc;
+  // (per-kernel timing creates events on demand: not inside this call)
+  const bool prof = d->eng->profiling;
+  d->eng->profiling = false;
+  rc = d->eng->decode_ws(ws, LDPC_NOALLOC_SCRATCH_BYTES, nframes, llr, llr_dtype, syndrome, max_iter, bits_out,
+                         iters_out, synd_out, status_out, llr_out, (hipStream_t)stream);
+  d->eng->profiling = prof;
+  return rc;
 }
 
 extern "C" int ldpc_decode_batch(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,

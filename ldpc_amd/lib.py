@@ -87,6 +87,7 @@ def load_library():
     L.ldpc_decoder_last_iterations.argtypes = [vp]
     L.ldpc_decode_batch.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp]
     L.ldpc_decode_batch_device.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]
+    L.ldpc_decode_batch_device_noalloc.argtypes = [vp, ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ldpc_decode_trace_q88.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, vp, cp, ip]
     L.ldpc_code_lds_schedule_stats.argtypes = [vp, ip, ip, vp]
     L.ldpc_code_vpass_place_stats.argtypes = [vp, ip, vp]
@@ -256,10 +257,14 @@ class Decoder:
         return out
 
     def decode_device(self, nframes, llr_ptr, llr_dtype, max_iter, syndrome_ptr=None, bits_ptr=None,
-                      iters_ptr=None, synd_ptr=None, status_ptr=None, llr_out_ptr=None, stream=None):
-        """Device-pointer form (integers / c_void_p, e.g. torch.Tensor.data_ptr())."""
+                      iters_ptr=None, synd_ptr=None, status_ptr=None, llr_out_ptr=None, stream=None,
+                      noalloc=False):
+        """Device-pointer form (integers / c_void_p, e.g. torch.Tensor.data_ptr()).
+        noalloc: the allocation-free variant (scratch in the library's static device array)."""
         vp = C.c_void_p
-        check(load_library().ldpc_decode_batch_device(
+        L = load_library()
+        fn = L.ldpc_decode_batch_device_noalloc if noalloc else L.ldpc_decode_batch_device
+        check(fn(
             self._h, int(nframes), vp(llr_ptr), int(llr_dtype), vp(syndrome_ptr), int(max_iter),
             vp(bits_ptr), vp(iters_ptr), vp(synd_ptr), vp(status_ptr), vp(llr_out_ptr), vp(stream)))
 

@@ -1,0 +1,146 @@
+"""ldpc_decode_batch_device_noalloc (the allocation-free entry point, include/ldpc_hip.h) against
+ldpc_decode_batch_device on the same device buffers, through the C ABI: two calls in a row, the
+second with fewer frames (the static scratch keeps the first call's contents), for a
+frame-resident decoder (scratch = frame queue head) and for two-pass decoders (scratch = message
+store and per-frame state); sizes beyond the 32 MiB are refused by code.  Bit-exact: both entry
+points run the same kernels."""
+import numpy as np
+import pytest
+
+from conftest import code_path, make_frames, to_q88
+
+pytestmark = pytest.mark.gpu
+
+
+class _Hip:
+    """Device buffers through the HIP runtime the library itself is linked to (no torch in the
+    process: one HIP runtime per process)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.held = []
+
+    def up(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(1, arr.nbytes)) == 0
+        assert self.rt.hipMemcpy(p, arr.ctypes.data_as(self.C.c_void_p), arr.nbytes, 1) == 0
+        self.held.append(p)
+        return p.value
+
+    def filled(self, shape, dtype, byte):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(1, n)) == 0
+        assert self.rt.hipMemset(p, byte, n) == 0
+        self.held.append(p)
+        return p.value
+
+    def down(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipDeviceSynchronize() == 0
+        assert self.rt.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.C.c_void_p(ptr), out.nbytes, 2) == 0
+        return out
+
+    def free(self):
+        for p in self.held:
+            self.rt.hipFree(p)
+        self.held = []
+
+
+def _run(hip, dec, code, inp, synd, it, noalloc, want_llr=False):
+    g = _Hip()
+    F = inp.shape[0]
+    d_in, d_sy = g.up(inp), g.up(synd)
+    bits = g.filled((F, code.n), np.uint8, 7)
+    sout = g.filled((F, code.m), np.uint8, 7)
+    iters = g.filled((F,), np.int32, 0xF7)
+    status = g.filled((F,), np.int32, 0xF7)
+    post = g.filled((F, code.n), np.float32, 0) if want_llr else None
+    dt = {np.dtype(np.int16): hip.DT.I16, np.dtype(np.float32): hip.DT.F32, np.dtype(np.float64): hip.DT.F64,
+          np.dtype(np.int32): hip.DT.I32}[inp.dtype]
+    try:
+        dec.decode_device(F, d_in, dt, it, d_sy, bits, iters, sout, status, post, None, noalloc=noalloc)
+        out = dict(bits=g.down(bits, (F, code.n), np.uint8), synd=g.down(sout, (F, code.m), np.uint8),
+                   iters=g.down(iters, (F,), np.int32), status=g.down(status, (F,), np.int32))
+        if want_llr:
+            out["llr"] = g.down(post, (F, code.n), np.float32)
+    finally:
+        g.free()
+    return out
+
+
+CASES = [
+    # code, algorithm, decoder options, frames of the first / second call, channel
+    ("1057.244.3.txt", "MINSUM_Q88", {}, 300, 41, 0.012),                       # frame-resident, int16 LLRs
+    ("204.33.484.txt", "MINSUM_F32", {}, 200, 37, 0.05),                       # frame-resident binary32
+    ("204.33.484.txt", "MINSUM_Q88", {"cn_variant": 5}, 700, 129, 0.05),       # two-pass, int16 messages, 2 slabs then 1
+    ("204.33.484.txt", "SPA_F32", {"want_llr": True}, 300, 50, 0.05),          # two-pass binary32 + posterior LLRs
+    ("204.33.484.txt", "SPA_TABLE_Q14", {"early_exit": True}, 260, 64, 0.04),  # two-pass int32, host early-exit polls
+]
+
+
+@pytest.mark.parametrize("name,alg,opts,f1,f2,p", CASES)
+def test_noalloc_equals_the_allocating_entry_point_twice_in_a_row(hip, oracle, name, alg, opts, f1, f2, p):
+    oc = oracle.load(code_path(name))
+    code = hip.Code.from_alist(code_path(name))
+    o = dict(early_exit=False)
+    o.update(opts)
+    dec = hip.Decoder(code, getattr(hip.ALG, alg), max_frames=1024, **o)
+    for F, seed in ((f1, 11), (f2, 12)):
+        x, s, llr = make_frames(oracle, oc, F, p, seed, "bsc")
+        if alg == "MINSUM_Q88":
+            inp = to_q88(llr)[1]
+        elif alg == "SPA_TABLE_Q14":
+            inp = oracle.float2fix14(llr).astype(np.int32)
+        else:
+            inp = llr.astype(np.float32)
+        sy = s.astype(np.uint8)
+        want_llr = bool(o.get("want_llr"))
+        ref = _run(hip, dec, code, inp, sy, 20, False, want_llr)
+        got = _run(hip, dec, code, inp, sy, 20, True, want_llr)
+        assert (ref["iters"] >= 0).all() and set(np.unique(ref["status"])) <= {0, 1}
+        if F == f1:
+            assert (ref["status"] == 0).any(), "the first call should hold frames that converge"
+        for k in ref:       # (the float sum-product keeps the reference's NaN hazards: NaN == NaN here)
+            assert np.array_equal(ref[k], got[k], equal_nan=(k == "llr")), (name, alg, F, k)
+    dec.close()
+
+
+def test_noalloc_refuses_what_does_not_fit_and_stays_usable(hip, oracle):
+    name = "Frolov_1024_0.5.txt"
+    oc = oracle.load(code_path(name))
+    code = hip.Code.from_alist(code_path(name))
+    # two-pass int16 engine: one slab of 512 frames of this code needs ~10 MB, four or more do not fit 32 MiB
+    dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=4096, early_exit=False, cn_variant=5)
+    F = 3585
+    x, s, llr = make_frames(oracle, oc, F, 0.03, 5, "bsc")
+    raw = to_q88(llr)[1]
+    sy = s.astype(np.uint8)
+    with pytest.raises(hip.LdpcError) as e:
+        _run(hip, dec, code, raw, sy, 10, True)
+    assert "static scratch" in str(e.value) and e.value.code == -4
+    with pytest.raises(hip.LdpcError) as e:                                   # poll slots were sized at create
+        _run(hip, dec, code, raw[:8], sy[:8], 1000, True)
+    assert "iterations" in str(e.value)
+    ref = _run(hip, dec, code, raw[:1000], sy[:1000], 10, False)
+    got = _run(hip, dec, code, raw[:1000], sy[:1000], 10, True)
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    # non-binary decoders are not served
+    g = hip.Code.from_alist(code_path("q4.sp.9000.6000.4500.1"))
+    gd = hip.Decoder(g, hip.ALG.GF2P_WHT, max_frames=2)
+    mem = _Hip()
+    z = mem.filled((1, g.n, 4), np.int32, 0)
+    with pytest.raises(hip.LdpcError) as e:
+        gd.decode_device(1, z, hip.DT.I32, 1, noalloc=True)
+    assert e.value.code == -6
+    mem.free()
+    dec.close()
+    gd.close()
