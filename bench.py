@@ -10,22 +10,45 @@ fires), LLR = +-log((1-p)/p) on the Q8.8 grid.  A "step" decodes one batch of
 dec() hold them) are resident in HBM before the timed region; outputs (decoded
 bits, iteration counts, status) are written to HBM.
 
-Prints ONE JSON line on rank 0.  value = decoded information Gbit/s over all
-ranks = K * frames * steps * ranks / seconds.  "roofline" is for the dominant
-kernel: algorithmic bytes per launch (check pass 2*E*b per frame,
-variable pass 2*E*b + n*b per frame, whole 10-iteration decode 10*(4*E*b+n*b))
-over its mean launch time from hipEvents recorded on the launch stream inside
-the timed region.  "cpu_baseline" times the CPU oracle (a port of the
-reference's dec(), oracle/ldpc_oracle.c) on a bounded sample of the same
-workload on rank 0.
+  python bench.py [--gpus N --steps K --warmup W --frames F --alg q88|f32|f64 --p 0.02]
 
-  python bench.py [--gpus N --steps K --warmup W --frames F --alg q88|f32 --p 0.02]
+--gpus N > 1 without a launcher's environment: this process starts N ranks of itself
+(`python -m torch.distributed.run --nproc-per-node N`, one rank per GPU, RCCL) before
+anything touches the GPU, and passes rank 0's line through.  Frames shard over the ranks
+with no data-path exchange (the reference's parfor batches, test_mex_B_float.m:24-30); the
+only collectives are the sum of the error counters (its `sum` over the workers' results,
+:73-78) and the max of the elapsed time.
+
+Prints ONE JSON line on rank 0.  value = decoded information Gbit/s over all
+ranks = K * frames * steps * ranks / seconds.
+
+"roofline" describes the dominant kernel of the timed region (its mean launch time from
+hipEvents on the launch stream):
+  * fused frame-resident kernels keep every message in LDS / VGPRs, so HBM is not what
+    bounds them: bound = "valu", achieved = vector wave-instructions per second
+    (SQ_INSTS_VALU per launch, counted by a rocprofv3 --pmc pass of this same command,
+    over the launch time), peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+    (MI355X_MICROARCH.md).  The SURVEY 8(d) figure -- algorithmic bytes of two-pass
+    flooding over the launch time -- is reported under "hbm_equivalent", never as frac.
+  * two-pass kernels move the algorithmic bytes: bound = "hbm".
+  "traffic" = HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (counter
+  unit KiB, FETCH doubled for gfx950 as the guide prescribes), taken by child processes
+  of this run at N=1 before the parent touches the GPU ("counters": "live"); when
+  rocprofv3 is unavailable the committed pass under profiles/ is used and named.
+"cpu_baseline" times the CPU oracle (a port of the reference's dec(),
+oracle/ldpc_oracle.c) on a bounded sample of the same workload: one process per core
+(cores = P) and the one-core figure.
 """
 import argparse
+import glob
 import json
 import math
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,17 +57,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CODE = os.path.join(ROOT, "tests", "golden", "codes", "peg_16000_3_0.9.txt")
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0        # 256 CUs x 4 SIMD-32, wave64 instruction = 2 cycles, 2.4 GHz
 SEED = 0x1DBC0001
+COMMITTED_COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per step per GPU")
-    ap.add_argument("--alg", default="q88", choices=["q88", "f32"])
+    ap.add_argument("--alg", default="q88", choices=["q88", "f32", "f64"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--p", type=float, default=0.02)
     ap.add_argument("--code", default=CODE)
@@ -52,22 +77,274 @@ def main():
     ap.add_argument("--cn-variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel hipEvents")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the binary32 leg reported under 'secondary'")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the floating-point leg reported under 'secondary'")
+    ap.add_argument("--no-pmc", action="store_true", help="no rocprofv3 counter passes (use the committed ones)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry", action="store_true",
+                    help="plumbing check without a GPU: gloo ranks, no decoding (tests/test_bench_launcher.py)")
+    ap.add_argument("--save-counters", default=None,
+                    help="write the live counter passes to this JSON (the committed fallback, profiles/r02_counters.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ launcher
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """N fresh rank processes of this script under torch.distributed.run (nothing in this
+    process has touched the GPU); rank 0's JSON line is passed through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit {r.returncode})", file=sys.stderr)
+        raise SystemExit(r.returncode or 1)
+    print(line, flush=True)
+
+
+# ------------------------------------------------------- counter passes (N=1)
+
+def pmc_sum(csv_path, kernel_substr):
+    """Per-counter sums and dispatch count over the dispatches of the kernels whose name holds
+    kernel_substr (rocprofv3 --pmc ... --output-format csv)."""
+    import csv
+    acc, disp = {}, set()
+    with open(csv_path) as f:
+        for r in csv.DictReader(f):
+            if kernel_substr not in r["Kernel_Name"]:
+                continue
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    return acc, len(disp)
+
+
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                      "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"]))
+
+
+def live_counters(args, kernel_substr):
+    """One rocprofv3 --pmc pass per counter group over `bench.py --pmc-child` (the same
+    workload, one launch), as children of this process before it touches the GPU.
+    -> {counter: value per launch} or None."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    base = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--gpus", "1", "--steps", "1", "--warmup", "0",
+             "--frames", str(args.frames), "--alg", args.alg, "--iters", str(args.iters), "--p", str(args.p),
+             "--code", args.code, "--early-exit", str(args.early_exit), "--cn-variant", str(args.cn_variant)]
+    try:
+        for tag, counters in PMC_PASSES:
+            d = os.path.join(base, tag)
+            cmd = [exe, "--pmc"] + counters + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                   text=True, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 pass '{tag}' timed out"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 pass '{tag}' failed (exit {r.returncode})"
+            acc, nd = pmc_sum(files[0], kernel_substr)
+            if nd == 0:
+                return None, f"no dispatch of a '{kernel_substr}' kernel in pass '{tag}'"
+            for k, v in acc.items():
+                out[k] = v / nd
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out, "live"
+
+
+def save_counters(args, counters):
+    """Merges this run's per-launch counters into the committed fallback file."""
+    doc = {}
+    if os.path.exists(args.save_counters):
+        with open(args.save_counters) as f:
+            doc = json.load(f)
+    doc["_comment"] = ("per-launch sums of rocprofv3 --pmc passes over `bench.py --pmc-child` (one launch of the bench "
+                       "workload): FETCH_SIZE / WRITE_SIZE in KiB (FETCH to be doubled on gfx950), SQ_* as counted; "
+                       "written by `bench.py --save-counters`; bench.py reads it only when a live pass is impossible")
+    doc[args.alg] = {"workload": f"peg_16000_3_0.9 {args.alg} {args.frames} frames/launch {args.iters} iterations",
+                     "frames_per_launch": args.frames, "per_launch": {k: float(v) for k, v in sorted(counters.items())}}
+    with open(args.save_counters, "w") as f:
+        json.dump(doc, f, indent=1)
+        f.write("\n")
+
+
+def committed_counters(args):
+    if args.code != CODE or args.iters != 10 or args.cn_variant != 0 or not os.path.exists(COMMITTED_COUNTERS):
+        return None
+    with open(COMMITTED_COUNTERS) as f:
+        t = json.load(f).get(args.alg)
+    if not t:
+        return None
+    scale = args.frames / t["frames_per_launch"]
+    return {k: v * scale for k, v in t["per_launch"].items()}
+
+
+# ------------------------------------------------------------- cpu baseline
+
+def _cpu_worker(job):
+    """Frames of the bench workload through the CPU oracle for ~seconds; -> (frames, seconds)."""
+    code_path, alg, iters, p, seconds, seed = job
+    from oracle.bindings import Oracle
+    ora = Oracle()
+    oc = ora.load(code_path)
+    n, m = oc.n, oc.m
+    rng = np.random.default_rng(seed)
+    L = math.log((1 - p) / p)
+    Lq = round(L * 256) / 256.0
+    s = np.zeros(m, np.int32)
+    fn = (lambda q: ora.dec_minsum_fixed(oc, q, s, iters, None, m + 1)) if alg == "q88" else \
+         (lambda q: ora.dec_minsum(oc, q, s, iters))
+    frames, spent = 0, 0.0
+    while spent < seconds or frames < 4:
+        q0 = np.where(rng.random(n) < p, -Lq, Lq).astype(np.float64)
+        t = time.perf_counter()
+        fn(q0)
+        spent += time.perf_counter() - t
+        frames += 1
+    return frames, spent
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, K_info):
+    """The CPU oracle (port of the reference dec(), O(dc^2) check node and all) on a bounded
+    sample of the same workload: one core, then one process per core of this process's share
+    of the host (the reference scales out the same way: one single-threaded worker per core,
+    test_mex_B_float.m:24-30)."""
+    import multiprocessing as mp
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    P = max(1, min(share, int(os.environ.get("OMP_NUM_THREADS", share)), 64))
+    f1, t1 = _cpu_worker((args.code, args.alg, args.iters, args.p, args.cpu_seconds * 0.4, SEED))
+    one = K_info * f1 / t1 / 1e9
+    jobs = [(args.code, args.alg, args.iters, args.p, args.cpu_seconds * 0.6, SEED + 1 + i) for i in range(P)]
+    w0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(P) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - w0
+    # aggregate rate = sum of the workers' own rates (each times only its dec() calls, as
+    # SURVEY 8(d) prescribes: not initdec, not the random numbers)
+    multi = sum(K_info * f / t for f, t in res) / 1e9
+    frames = sum(f for f, _ in res)
+    return {"value": round(multi, 6), "unit": "Gbit/s", "cores": P, "kind": "port", "cpu_model": cpu_model(),
+            "one_core": {"value": round(one, 6), "frames": f1, "seconds": round(t1, 2)},
+            "sample": f"{frames} frames of the same workload through oracle/ldpc_oracle.c (restatement of the "
+                      f"reference dec(), gcc -O2), {P} single-threaded processes side by side for "
+                      f"{args.cpu_seconds * 0.6:.0f} s each ({wall:.1f} s wall incl. start-up); one_core: {f1} frames, "
+                      f"one process alone"}
+
+
+# --------------------------------------------------------------------- main
+
+def dry_run(args, rank, world):
+    """The rank plumbing without a GPU or the library: gloo group, barrier, the two
+    all-reduces, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rs = world
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rank + 1, 1], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        assert int(c[0]) == world * (world + 1) // 2
+        rs = int(c[1])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no decoding)", "value": 0.0, "unit": "Gbit/s", "n_gpus": world,
+                          "ranks_in_reduce": rs, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dry": True}), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        launch_ranks(args)
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry:
+        dry_run(args, rank, world)
+        return
+
+    b_msg = {"q88": 2, "f32": 4, "f64": 8}[args.alg]
+    fused_possible = args.cn_variant == 0 and os.environ.get("LDPC_HIP_FUSED", "1") != "0"
+
+    # Legs that start child processes come first: nothing here has touched the GPU yet.
+    counters, counters_src, cpu = None, None, None
+    if rank == 0 and world == 1 and not args.pmc_child:
+        if not args.no_pmc:
+            counters, counters_src = live_counters(args, "fused_" if fused_possible else "cn_")
+        if counters is not None and args.save_counters:
+            save_counters(args, counters)
+        if counters is None:
+            why = counters_src
+            counters = committed_counters(args)
+            counters_src = None if counters is None else \
+                f"committed pass {os.path.relpath(COMMITTED_COUNTERS, ROOT)}" + (f" ({why})" if why else "")
+        if not args.no_cpu:
+            code_n_m = np.loadtxt(args.code, max_rows=1, dtype=int)
+            cpu = cpu_baseline(args, int(code_n_m[0] - code_n_m[1]))
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libldpc_hip has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     import ldpc_amd
     from ldpc_amd import ALG, DT
@@ -76,8 +353,7 @@ def main():
     n, m, E = code.n, code.m, code.E
     K_info = n - m
     F = args.frames
-    alg = ALG.MINSUM_Q88 if args.alg == "q88" else ALG.MINSUM_F32
-    b_msg = 2 if args.alg == "q88" else 4
+    alg = {"q88": ALG.MINSUM_Q88, "f32": ALG.MINSUM_F32, "f64": ALG.MINSUM_F64}[args.alg]
     dec = ldpc_amd.Decoder(code, alg, device=local_rank, max_frames=F, early_exit=bool(args.early_exit),
                            cn_variant=args.cn_variant)
 
@@ -90,9 +366,12 @@ def main():
     if args.alg == "q88":
         llr = torch.where(flips, -Lraw, Lraw).to(torch.int16).contiguous()
         dt = DT.I16
-    else:
+    elif args.alg == "f32":
         llr = torch.where(flips, -L, L).to(torch.float32).contiguous()
         dt = DT.F32
+    else:
+        llr = torch.where(flips, -L, L).to(torch.float64).contiguous()
+        dt = DT.F64
     del flips
     bits = torch.empty((F, n), dtype=torch.uint8, device=dev)
     iters = torch.empty(F, dtype=torch.int32, device=dev)
@@ -123,6 +402,8 @@ def main():
     if not args.no_profile:
         ms_k, cnt_k = dec.profile_read()
         dec.profile(False)
+    if args.pmc_child:
+        return
 
     # the path's only collective: error counters (and the max of the elapsed time)
     fails = int((status != 0).sum().item())
@@ -132,21 +413,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([fails, undet], dtype=torch.int64, device=dev)
+        c = torch.tensor([fails, undet, 1], dtype=torch.int64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         fails, undet = int(c[0].item()), int(c[1].item())
+        assert int(c[2].item()) == world, "a rank is missing from the counter reduce"
 
-    # configs[1] names both number formats: the other one (binary32 when the headline is Q8.8)
-    # is timed the same way on the same code, right after, and reported under "secondary"
+    # configs[1] names both number formats: the float min-sum in the reference's own
+    # precision (binary64, test_code_min_sum_B.c) is timed the same way on the same frames,
+    # right after, and reported under "secondary"
     secondary = None
     if args.alg == "q88" and not args.no_secondary:
         del dec
-        dec2 = ldpc_amd.Decoder(code, ALG.MINSUM_F32, device=local_rank, max_frames=F, early_exit=bool(args.early_exit))
-        llr2 = (llr.to(torch.float32) * (L / Lraw)).contiguous()
-        s_steps = max(1, args.steps // 2)
+        sF = min(F, 16384)
+        dec2 = ldpc_amd.Decoder(code, ALG.MINSUM_F64, device=local_rank, max_frames=sF, early_exit=bool(args.early_exit))
+        llr2 = (llr[:sF].to(torch.float64) * (L / Lraw)).contiguous()
+        s_steps = max(1, args.steps // 4)
 
         def step2():
-            dec2.decode_device(F, llr2.data_ptr(), DT.F32, args.iters, None, bits.data_ptr(), iters.data_ptr(), None,
+            dec2.decode_device(sF, llr2.data_ptr(), DT.F64, args.iters, None, bits.data_ptr(), iters.data_ptr(), None,
                                status.data_ptr(), None, stream)
         step2()
         fence()
@@ -159,16 +443,15 @@ def main():
             t = torch.tensor([el2], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
-        secondary = {"alg": "MINSUM_F32 (binary32 twin of the reference's double min-sum, fused kernel)",
-                     "value": round(K_info * F * s_steps * world / el2 / 1e9, 3), "unit": "Gbit/s",
-                     "steps": s_steps, "ms_per_step": round(el2 / s_steps * 1e3, 3), "dtype": "f32",
-                     "avg_iterations": round(float(iters.float().mean().item()), 3)}
+        secondary = {"alg": "MINSUM_F64 (the reference's double min-sum, test_code_min_sum_B.c:137-208, bit-exact)",
+                     "value": round(K_info * sF * s_steps * world / el2 / 1e9, 3), "unit": "Gbit/s",
+                     "frames_per_step_per_gpu": sF, "steps": s_steps, "ms_per_step": round(el2 / s_steps * 1e3, 3),
+                     "dtype": "f64", "avg_iterations": round(float(iters[:sF].float().mean().item()), 3)}
         del dec2, llr2
 
     if rank == 0:
         total_frames = F * args.steps * world
         value = K_info * total_frames / elapsed / 1e9
-        # dominant kernel
         names = ["vn_kernel", "cn_kernel", "fused_decode_kernel", "other"]
         per_launch_bytes = [(2 * E * b_msg + n * b_msg) * F, 2 * E * b_msg * F,
                             args.iters * (4 * E * b_msg + n * b_msg) * F, 0]
@@ -176,83 +459,63 @@ def main():
         if cnt_k.sum() > 0:
             k = int(np.argmax(ms_k))
             avg_ms = ms_k[k] / max(1, cnt_k[k])
-            ach = per_launch_bytes[k] / (avg_ms * 1e-3) / 1e9
-            traffic = measured_traffic(names[k], args, F)
-            roofline = {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt_k[k]),
-                        "algorithmic_bytes_per_launch": per_launch_bytes[k],
-                        "figure": "achieved = SURVEY 8(d) ALGORITHMIC bytes of two-pass flooding (every edge "
-                                  "message crossing HBM once per direction per iteration) / launch time; the "
-                                  "fused kernel keeps messages in LDS/VGPRs, so frac > 1 is possible and is "
-                                  "NOT physical HBM bandwidth -- 'traffic' (PMC FETCH+WRITE bytes per launch) "
-                                  "is what actually moved" if names[k] == "fused_decode_kernel" else
-                                  "achieved = algorithmic bytes per launch / launch time",
-                        "actual_hbm_GBps": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
-                        "all_kernels_ms": {names[i]: round(float(ms_k[i]), 3) for i in range(4) if cnt_k[i]}}
+            sec = avg_ms * 1e-3
+            ach_hbm = per_launch_bytes[k] / sec / 1e9
+            traffic = None
+            if counters and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                # KiB units; FETCH_SIZE tallies 128-B requests at 64 B on gfx950: doubled (MI355X_MICROARCH.md)
+                traffic = int(round((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024))
+            common = {"kernel": names[k], "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                      "launches": int(cnt_k[k]), "counters": counters_src,
+                      "actual_hbm_GBps": None if traffic is None else round(traffic / sec / 1e9, 1),
+                      "all_kernels_ms": {names[i]: round(float(ms_k[i]), 3) for i in range(4) if cnt_k[i]}}
+            if names[k] == "fused_decode_kernel":
+                insts = counters.get("SQ_INSTS_VALU") if counters else None
+                ach = None if insts is None else insts / sec / 1e9
+                roofline = {"bound": "valu", "achieved": None if ach is None else round(ach, 1),
+                            "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                            "frac": None if ach is None else round(ach / VALU_PEAK_GINST, 4),
+                            "valu_wave_instructions_per_launch": None if insts is None else int(insts),
+                            "figure": "vector ALU issue: SQ_INSTS_VALU per launch / launch time against 1024 SIMDs x "
+                                      "2.4 GHz / 2 cycles per wave64 instruction; messages never leave LDS / VGPRs, "
+                                      "so the HBM roofline does not bound this kernel",
+                            "hbm_equivalent": {"algorithmic_bytes_per_launch": per_launch_bytes[k],
+                                               "GBps": round(ach_hbm, 1), "over_hbm_peak": round(ach_hbm / HBM_PEAK_GBS, 4),
+                                               "note": "SURVEY 8(d) two-pass algorithmic bytes / launch time: an "
+                                                       "equivalence figure, NOT bandwidth moved and not a roofline "
+                                                       "fraction"}}
+                if counters and counters.get("SQ_WAVE_CYCLES"):
+                    wc = counters["SQ_WAVE_CYCLES"]
+                    roofline["sq"] = {c: round(counters[c] / wc, 4) for c in
+                                      ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c in counters}
+                    roofline["sq"]["note"] = "shares of SQ_WAVE_CYCLES, from the profiled (lower-clocked) pass"
+            else:
+                roofline = {"bound": "hbm", "achieved": round(ach_hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach_hbm / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": per_launch_bytes[k],
+                            "figure": "algorithmic bytes per launch (SURVEY 8d) / launch time"}
+            roofline.update(common)
         whole = args.iters * (4 * E * b_msg + n * b_msg) * total_frames / elapsed / 1e9 / world
-        cpu = None
-        if not args.no_cpu:
-            cpu = cpu_baseline(args, n, m, K_info)
-        out_secondary = secondary
+        fmt = {"q88": "Q8.8 fixed-point", "f32": "binary32", "f64": "binary64"}[args.alg]
         out = {
             "metric": "decoded information throughput, N=16000 R=0.9 min-sum, 10 iterations",
             "value": round(value, 3), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i16" if args.alg == "q88" else "f32", "data": "synthetic",
-            "config": {"workload": f"peg_16000_3_0.9 {'Q8.8 fixed-point' if args.alg == 'q88' else 'binary32'} "
-                                   f"min-sum, {args.iters} iterations executed per frame, BSC p={args.p}, "
-                                   f"all-zero codeword", "frames_per_step_per_gpu": F,
+            "dtype": {"q88": "i16", "f32": "f32", "f64": "f64"}[args.alg], "data": "synthetic",
+            "config": {"workload": f"peg_16000_3_0.9 {fmt} min-sum, {args.iters} iterations executed per frame, "
+                                   f"BSC p={args.p}, all-zero codeword", "frames_per_step_per_gpu": F,
                        "total_frames": total_frames, "n": n, "m": m, "edges": E,
-                       "early_exit": args.early_exit, "parallelism": f"frames sharded over {world} GPU(s)"},
+                       "early_exit": args.early_exit, "parallelism": f"frames sharded over {world} GPU(s)",
+                       "ranks": world},
             "avg_iterations": round(avg_it, 3), "frame_failures": fails, "undetected": undet,
-            "whole_decode_algorithmic_GBps_per_gpu": round(whole, 1),
-            "whole_decode_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+            "hbm_equivalent_GBps_per_gpu": round(whole, 1),
             "roofline": roofline, "cpu_baseline": cpu,
-            "secondary": out_secondary,
+            "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-
-
-def measured_traffic(kernel, args, F):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), scaled by
-    frames per launch; None when no pass was taken for this kernel / workload."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if args.code != CODE or args.iters != 10 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        t = json.load(f).get(args.alg)
-    if not t or t.get("kernel") != kernel:
-        return None
-    return int(round(t["hbm_bytes_per_frame"] * F))
-
-
-def cpu_baseline(args, n, m, K_info):
-    """The CPU oracle (port of the reference dec(), O(dc^2) check node and all) on a
-    bounded sample of the same workload, one core."""
-    from oracle.bindings import Oracle
-    ora = Oracle()
-    oc = ora.load(args.code)
-    rng = np.random.default_rng(SEED)
-    L = math.log((1 - args.p) / args.p)
-    Lq = round(L * 256) / 256.0
-    s = np.zeros(m, np.int32)
-    frames = 0
-    spent = 0.0
-    fn = (lambda q: ora.dec_minsum_fixed(oc, q, s, args.iters, None, m + 1)) if args.alg == "q88" else \
-         (lambda q: ora.dec_minsum(oc, q, s, args.iters))
-    while spent < args.cpu_seconds or frames < 8:
-        q0 = np.where(rng.random(n) < args.p, -Lq, Lq).astype(np.float64)
-        t = time.perf_counter()
-        fn(q0)
-        spent += time.perf_counter() - t
-        frames += 1
-    return {"value": round(K_info * frames / spent / 1e9, 6), "unit": "Gbit/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} frames of the same workload ({spent:.1f} s) through oracle/ldpc_oracle.c "
-                      f"(restatement of the reference dec(), -O2, one thread)"}
 
 
 if __name__ == "__main__":
