@@ -58,7 +58,8 @@ int ldpc_code_load_alist(const char *path, ldpc_code **out);
 
 /* Graph handed over as arrays, the shape of the WD-farm boundary
  * (WD_farm/GFq_LDPC.c:477): row_ptr[m+1], col_idx[E] 0-based, hval[E] or NULL
- * (binary).  q = 2 for binary codes. */
+ * (binary).  q = 2 for binary codes.  LDPC_ERR_FORMAT unless row_ptr starts at 0 and is
+ * monotone, every column is in range and no variable appears twice in a row. */
 int ldpc_code_from_csr(int n, int m, int q, const int32_t *row_ptr,
                        const int32_t *col_idx, const int32_t *hval, ldpc_code **out);
 
@@ -87,7 +88,8 @@ typedef enum ldpc_alg {
   LDPC_ALG_MINSUM_Q88    = 2, /* dec(), test_code_min_sum_B_fixed.c:192-316, int16 Q8.8        */
   LDPC_ALG_SPA_F32       = 3, /* dec(), test_code_B_float.c:134-199, binary32 messages: logtanh2 /
                                  atanh2 evaluated without cancellation, logprod summed in binary64,
-                                 so that it follows the reference's double past |LLR| ~ 17        */
+                                 so that it follows the reference's double past |LLR| ~ 17; a zero
+                                 message is floored at 2^-100 (no log tanh(0) = -inf -> NaN)      */
   LDPC_ALG_SPA_F64       = 4, /* same in binary64                                              */
   LDPC_ALG_SPA_TABLE_Q14 = 5, /* dec(), test_code_B.c:171-233 / test_code_no_mex_B.c:170-242   */
   LDPC_ALG_GF2P_WHT      = 6, /* dec(), GFq_LDPC_NTT.c:437-544, GF(2^p) integer WHT domain     */
@@ -284,7 +286,10 @@ int  ldpc_mc_last_pass(ldpc_mc *mc, int nframes, uint8_t *x, uint8_t *bits, int3
  * functions; `errors` is the caller's double[2] = {not converged, converged to
  * a word != x}.  They return LDPC_OK or a negative code instead of void.
  * The graph/decoder for `code_filename` is cached per process and device 0 is
- * used (set LDPC_HIP_DEVICE to override).                                   */
+ * used (set LDPC_HIP_DEVICE to override).  The cached decoders are shared, so
+ * these entry points are serialised per process by one lock (the reference's
+ * functions work in file-scope globals and are not re-entrant either); for
+ * concurrent decoding use one ldpc_decoder per host thread.                  */
 
 /* test_code_min_sum_B(), test_code_min_sum_B.c:331-359 (single frame, caller's x,s,y,q0) */
 int test_code_min_sum_B(const char *code_filename, int iteration, int *x, int *s, int *y,
@@ -294,7 +299,10 @@ int test_code_min_sum_B_cw_noise_gen(const char *code_filename, int iteration, i
                                      double p_bsc, double *errors);
 /* test_code_min_sum_B() of test_code_min_sum_B_fixed.c:442-473.  The reference
  * reuses the float function's name with one more argument; in one C library
- * the symbol needs its own name.  Verilog_sim_filename may be NULL (no trace);
+ * the symbol needs its own name.  q0 must hold Q8.8 values (k/256 in [-128, 127], what the
+ * reference's bsc() :117-120 produces): the reference passes q0 to dec() unquantised, the
+ * int16 decoder is its arithmetic exactly on such values only, and any other q0 is refused
+ * with LDPC_ERR_UNSUPPORTED rather than rounded.  Verilog_sim_filename may be NULL (no trace);
  * otherwise the message trace of _fixed.c:245-260,:288-296 is written (the
  * trace is produced by a host replay).                  */
 int test_code_min_sum_B_fixed(const char *code_filename, int iteration, int *x, int *s, int *y,
@@ -325,6 +333,17 @@ int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, i
  * and is column-normalised in place like the reference (:548-558).         */
 int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
              int num_reads, int decode_mode, double *p_rec_given_sent, double *errors);
+
+/* The inputs of GFq_LDPC()'s trials for a given generator state, for inspection: per frame
+ * x[n] (x[i] = rand() % Q, :626), s[m] = enc(x) (:632), the reads y[n] drawn by channel()
+ * (:213-231), logfna[n][q] = log P(a sent | y_i) with the -100 floor (assign_llr, :199-211,
+ * tables from make_p_sent_given_rec_T, :177-197) and the percent-granular uniform draws
+ * rand_select[n] behind y (the reference takes them from rand(), seeded from the clock, so
+ * the stream itself cannot be matched; the channel law can, draw by draw).  p_rec_given_sent
+ * is column-normalised in place.  s, y, rand_select may be NULL.  Host only; needs no GPU. */
+int GFq_LDPC_experiment(const char *code_filename, int num_reads, double *p_rec_given_sent,
+                        uint64_t seed, int nframes, int32_t *x, int32_t *s, int32_t *y,
+                        double *logfna, float *rand_select);
 
 /* GFq_LDPC() of WD_farm/GFq_LDPC.c:477 (mex gateway :635-709): same harness, but the graph is
  * passed in as the flat arrays WD_farm/InitSumProductDecoderSyndrome.m builds, row-major and

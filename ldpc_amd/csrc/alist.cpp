@@ -63,6 +63,11 @@ int ldpc_finish_code(ldpc_code &c, std::string &err) {
     err = "inconsistent CSR arrays";
     return LDPC_ERR_FORMAT;
   }
+  if (c.row_ptr[0] != 0) { err = "row_ptr[0] is not 0"; return LDPC_ERR_FORMAT; }
+  if ((int)c.col_idx.size() != E || (!c.hval.empty() && (int)c.hval.size() != E)) {
+    err = "inconsistent CSR arrays";
+    return LDPC_ERR_FORMAT;
+  }
   if (c.hval.empty()) c.hval.assign(E, 1);
   std::vector<int32_t> deg(c.n, 0);
   c.rmax = 0;
@@ -81,6 +86,19 @@ int ldpc_finish_code(ldpc_code &c, std::string &err) {
       return LDPC_ERR_FORMAT;
     }
     deg[v]++;
+  }
+  // a variable twice in one row is not a parity-check matrix entry (over GF(2) the two would
+  // cancel); the kernels' slot tables match edges by position and would decode another graph
+  {
+    std::vector<int32_t> last(c.n, -1);
+    for (int j = 0; j < c.m; j++)
+      for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) {
+        if (last[c.col_idx[e]] == j) {
+          err = "row " + std::to_string(j) + " holds variable " + std::to_string(c.col_idx[e]) + " twice";
+          return LDPC_ERR_FORMAT;
+        }
+        last[c.col_idx[e]] = j;
+      }
   }
   c.col_ptr.assign(c.n + 1, 0);
   c.cmax = 0;

@@ -233,8 +233,13 @@ template <typename A> struct CnStateMin {
 // the cancellation: log tanh(a/2) = -2 atanh(e^-a) by its series once a > 3, and
 // log((1 - e^-a) / (1 + e^-a)) below (1 - e^-a from its series under 0.25), and
 // 2 atanh(e^x) with 1 - e^x from the series of -expm1(x) above -0.1 and the atanh series
-// below -3.  Worst relative error against exact arithmetic 9e-7 (binary32 rounding).  Values at 0, -inf and NaN stay the
-// reference's.
+// below -3.  Worst relative error against exact arithmetic 9e-7 (binary32 rounding).  Values at -inf and NaN stay the
+// reference's; a ZERO message is floored at 2^-100 (log tanh = -69.8 instead of -inf): the reference's
+// -inf - (-inf) = NaN on the leave-one-out of a zero edge (test_code_B_float.c:149,168) needs an exact
+// cancellation in the variable sum, which binary32 rounding produces on frames where the reference's double
+// has none (seen on 1 of 530 equal-magnitude frames of 1057.244.3: NaN here, a codeword after 10 iterations
+// there); with the floor the zero edge gets the product of the others and the others get ~0, as in exact arithmetic.
+#define SPA_F32_MINMAG 0x1p-100f
 // v_exp_f32 / v_log_f32 / v_rcp_f32 directly (1 ulp): __expf / __logf wrap them in denormal
 // range handling and __fdividef compiles to the IEEE division sequence (measured: 96 v_div_fmas
 // and 400 compares in the register kernel).  The arguments here never need either: log of a
@@ -242,6 +247,7 @@ template <typename A> struct CnStateMin {
 __device__ __forceinline__ float spa_fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float spa_flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 __device__ __forceinline__ float spa_logtanh2(float a) {
+  a = a < SPA_F32_MINMAG ? SPA_F32_MINMAG : a;   // (a NaN stays a NaN)
   const float t = spa_fexp(-a);             // tanh(a/2) = (1 - t) / (1 + t): one exp, no tanhf
   if (a > 3.0f) { const float t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
   float num = 1.0f - t;

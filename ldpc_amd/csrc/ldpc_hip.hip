@@ -69,9 +69,12 @@ extern "C" int ldpc_code_from_csr(int n, int m, int q, const int32_t *row_ptr, c
   c->n = n;
   c->m = m;
   c->q = q;
+  // nothing is read through row_ptr before it has been checked
+  if (row_ptr[0] != 0) { ldpc_set_error("row_ptr[0] is not 0"); return LDPC_ERR_FORMAT; }
+  for (int j = 0; j < m; j++)
+    if (row_ptr[j + 1] < row_ptr[j]) { ldpc_set_error("row_ptr not monotone"); return LDPC_ERR_FORMAT; }
   c->row_ptr.assign(row_ptr, row_ptr + m + 1);
   const int E = row_ptr[m];
-  if (E < 0) return LDPC_ERR_ARG;
   c->col_idx.assign(col_idx, col_idx + E);
   if (hval) c->hval.assign(hval, hval + E);
   std::string err;

@@ -26,6 +26,11 @@ namespace {
 // (test_code_min_sum_B.c:289), so its Monte-Carlo streams are not reproducible
 // by design; a splitmix64 stream with an optional fixed seed stands in.
 std::mutex g_mu;
+// The reference-shaped entry points share cached decoders (one per code file and algorithm), and a
+// decoder is not re-entrant: calls are serialised per process, like the reference's own
+// file-scope-global decoders, which are not re-entrant either.
+std::recursive_mutex g_call_mu;
+#define SERIALISED std::lock_guard<std::recursive_mutex> call_lock_(g_call_mu)
 uint64_t g_state = 0;
 bool g_seeded = false;
 
@@ -198,6 +203,23 @@ int single_frame(const char *file, int alg, int iteration, const int *x, const i
   int rc = get_decoder(file, alg, &code, &dec);
   if (rc) return rc;
   const int n = ldpc_code_n(code), m = ldpc_code_m(code);
+  if (alg == LDPC_ALG_MINSUM_Q88) {
+    // The reference hands q0 to dec() untouched (test_code_min_sum_B_fixed.c:442-459): its sums
+    // (:214-220, :299-303), the iteration-0 test (:199-207) and the trace (:250-256) see the raw
+    // doubles, only the v2c magnitudes go through float_to_fix.  The int16 decoder is that
+    // arithmetic exactly when q0 is on the Q8.8 grid and inside float_to_fix's range -- what the
+    // reference's own bsc() (:117-120) and Verilog tester (11/256) produce.  Anything else would
+    // be quantised here and could decode differently (q0 = -0.001: bit 1 there, 0 here): refused.
+    for (int i = 0; i < n; i++) {
+      const double r = q0[i] * 256.0;
+      if (!(r == std::nearbyint(r)) || q0[i] > 127.0 || q0[i] < -128.0) {
+        ldpc_set_error("test_code_min_sum_B_fixed: q0[" + std::to_string(i) + "] = " + std::to_string(q0[i]) +
+                       " is not a Q8.8 value (k/256 in [-128, 127]); the fixed-point decoder takes on-grid "
+                       "LLRs only (put them through float_to_fix first, as the reference's bsc() does)");
+        return LDPC_ERR_UNSUPPORTED;
+      }
+    }
+  }
   std::vector<uint8_t> sy(m), bits(n);
   for (int j = 0; j < m; j++) sy[j] = (uint8_t)(s[j] & 1);
   int32_t status = 1;
@@ -231,46 +253,54 @@ extern "C" void ldpc_set_seed(uint64_t seed) {
 
 extern "C" int test_code_min_sum_B(const char *code_filename, int iteration, int *x, int *s, int *y,
                                    double *q0, double *errors) {
+  SERIALISED;
   (void)y;   // unused by the reference's dec() as well
   return single_frame(code_filename, LDPC_ALG_MINSUM_F64, iteration, x, s, q0, errors, nullptr);
 }
 
 extern "C" int test_code_min_sum_B_cw_noise_gen(const char *code_filename, int iteration, int trials,
                                                 double p_bsc, double *errors) {
+  SERIALISED;
   return monte_carlo_bsc(code_filename, LDPC_ALG_MINSUM_F64, iteration, trials, p_bsc, true, PREP_NONE,
                          errors);
 }
 
 extern "C" int test_code_min_sum_B_fixed(const char *code_filename, int iteration, int *x, int *s, int *y,
                                          double *q0, double *errors, const char *Verilog_sim_filename) {
+  SERIALISED;
   (void)y;
   return single_frame(code_filename, LDPC_ALG_MINSUM_Q88, iteration, x, s, q0, errors, Verilog_sim_filename);
 }
 
 extern "C" int test_code_min_sum_B_fixed_cw_noise_gen(const char *code_filename, int iteration, int trials,
                                                       double p_bsc, double *errors) {
+  SERIALISED;
   return monte_carlo_bsc(code_filename, LDPC_ALG_MINSUM_Q88, iteration, trials, p_bsc, true, PREP_Q88,
                          errors);
 }
 
 extern "C" int test_code_B_float(const char *code_filename, int iteration, int *x, int *s, int *y,
                                  double *q0, double *errors) {
+  SERIALISED;
   (void)y;
   return single_frame(code_filename, LDPC_ALG_SPA_F64, iteration, x, s, q0, errors, nullptr);
 }
 
 extern "C" int test_code_B_float_cw_noise_gen(const char *code_filename, int iteration, int trials,
                                               double p_bsc, double *errors) {
+  SERIALISED;
   return monte_carlo_bsc(code_filename, LDPC_ALG_SPA_F64, iteration, trials, p_bsc, true, PREP_NONE, errors);
 }
 
 extern "C" int test_code_B(int iteration, int trials, double p_bsc, const char *H_file, double *errors) {
+  SERIALISED;
   return monte_carlo_bsc(H_file, LDPC_ALG_SPA_TABLE_Q14, iteration, trials, p_bsc, false, PREP_Q14, errors);
 }
 
 // test_code_B_MSDP(), test_code_B_MSDP.c:442-543
 extern "C" int test_code_B_MSDP(const char *code_filename, int iteration, int num_trials, int num_reads,
                                 int decode_mode, double *p_rec_given_sent, double *errors) {
+  SERIALISED;
   if (!errors) return LDPC_ERR_ARG;
   errors[0] = errors[1] = 0;
   if (!p_rec_given_sent || (num_reads != 1 && num_reads != 3) || num_trials < 0 || iteration < 0) return LDPC_ERR_ARG;
@@ -305,6 +335,55 @@ extern "C" int test_code_B_MSDP(const char *code_filename, int iteration, int nu
   return LDPC_OK;
 }
 
+// The channel front-end of GFq_LDPC() (GFq_LDPC.c:177-248), host side: the tables once per
+// call, then one frame at a time.
+struct GfqChannel {
+  int Q = 0, R = 0;
+  const double *p = nullptr;            // p_rec_given_sent [R][Q], column-normalised
+  std::vector<double> logT;             // log p_sent_given_rec_T [R][Q], floor -100 (:204-206)
+
+  // column normalisation in place (:548-558), then make_p_sent_given_rec_T() (:177-197)
+  void prepare(int q, int num_reads, double *p_rec_given_sent) {
+    Q = q; R = q * num_reads; p = p_rec_given_sent;
+    for (int i = 0; i < Q; i++) {
+      double norm = 0;
+      for (int j = 0; j < R; j++) norm += p_rec_given_sent[j * Q + i];
+      for (int j = 0; j < R; j++) p_rec_given_sent[j * Q + i] /= norm;
+    }
+    logT.assign((size_t)R * Q, 0.0);
+    const double P_x = 1 / (1.0 * Q);
+    for (int i = 0; i < R; i++) {
+      double P_y = 0;
+      for (int j = 0; j < Q; j++) P_y += p_rec_given_sent[i * Q + j] * P_x;
+      for (int j = 0; j < Q; j++) {
+        const double t = P_y ? P_x * p_rec_given_sent[i * Q + j] / P_y : 0.0;
+        logT[(size_t)i * Q + j] = t == 0 ? -100.0 : std::log(t);
+      }
+    }
+  }
+  // channel() (:213-248) for one symbol: the read y drawn by walking the column of x with
+  // the percent-granular draw `sel` (the reference: rand() * 100 / RAND_MAX as floats)
+  int draw(int xi, float sel) const {
+    double temp = 0;
+    int rec = 0;
+    if (!sel)
+      while (rec < R && !p[(rec++) * Q + xi]) {}
+    while (temp < sel && rec != R) temp += 100 * p[(rec++) * Q + xi];
+    return rec > 0 ? rec - 1 : 0;
+  }
+  // one frame: x[i] = rand() % Q (:626), y, logfna[i][*] (frame-major rows of Q); sel_out optional
+  void frame(Rng &r, int n, int32_t *xf, int32_t *yf, double *lf, float *sel_out) const {
+    for (int i = 0; i < n; i++) xf[i] = (int32_t)r.below((uint32_t)Q);
+    for (int i = 0; i < n; i++) {
+      const float sel = (float)(r.next() >> 40) * 100.0f / (float)((1u << 24) - 1);
+      const int yi = draw(xf[i], sel);
+      if (yf) yf[i] = yi;
+      if (sel_out) sel_out[i] = sel;
+      memcpy(&lf[(size_t)i * Q], &logT[(size_t)yi * Q], sizeof(double) * Q);
+    }
+  }
+};
+
 // The trial loop of GFq_LDPC(), GFq_LDPC.c:540-655 (same in WD_farm/GFq_LDPC.c:477-633), on a
 // given graph and decoder.
 static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num_trials, int num_reads,
@@ -319,26 +398,9 @@ static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num
     return LDPC_ERR_UNSUPPORTED;
   }
   int rc;
-  HostGraph g(code);
-  const int Q = g.q, n = g.n, m = g.m, R = Q * num_reads;
-
-  // column normalisation in place, :548-558
-  for (int i = 0; i < Q; i++) {
-    double norm = 0;
-    for (int j = 0; j < R; j++) norm += p_rec_given_sent[j * Q + i];
-    for (int j = 0; j < R; j++) p_rec_given_sent[j * Q + i] /= norm;
-  }
-  // make_p_sent_given_rec_T(), :177-197, kept as log values with the -100 floor of :204-206
-  std::vector<double> logT((size_t)R * Q);
-  const double P_x = 1 / (1.0 * Q);
-  for (int i = 0; i < R; i++) {
-    double P_y = 0;
-    for (int j = 0; j < Q; j++) P_y += p_rec_given_sent[i * Q + j] * P_x;
-    for (int j = 0; j < Q; j++) {
-      const double t = P_y ? P_x * p_rec_given_sent[i * Q + j] / P_y : 0.0;
-      logT[(size_t)i * Q + j] = t == 0 ? -100.0 : std::log(t);
-    }
-  }
+  const int Q = ldpc_code_q(code), n = ldpc_code_n(code), m = ldpc_code_m(code);
+  GfqChannel ch;
+  ch.prepare(Q, num_reads, p_rec_given_sent);
 
   Rng r = take_rng();
   const int B = ldpc_decoder_max_frames(dec);
@@ -349,20 +411,9 @@ static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num
     const int nf = num_trials - t0 < B ? num_trials - t0 : B;
     for (int f = 0; f < nf; f++) {
       int32_t *xf = &x[(size_t)f * n];
-      for (int i = 0; i < n; i++) xf[i] = (int32_t)r.below((uint32_t)Q);
+      ch.frame(r, n, xf, nullptr, &logfna[(size_t)f * n * Q], nullptr);
       ldpc_code_syndrome(code, xf, sx.data());
       for (int j = 0; j < m; j++) s[(size_t)f * m + j] = (uint8_t)sx[j];
-      // channel(), :213-248
-      for (int i = 0; i < n; i++) {
-        double temp = 0;
-        int rec = 0;
-        const float sel = (float)(r.next() >> 40) * 100.0f / (float)((1u << 24) - 1);
-        if (!sel)
-          while (rec < R && !p_rec_given_sent[(rec++) * Q + xf[i]]) {}
-        while (temp < sel && rec != R) temp += 100 * p_rec_given_sent[(rec++) * Q + xf[i]];
-        const int yi = rec > 0 ? rec - 1 : 0;
-        memcpy(&logfna[((size_t)f * n + i) * Q], &logT[(size_t)yi * Q], sizeof(double) * Q);
-      }
     }
     rc = ldpc_decode_batch(dec, nf, logfna.data(), LDPC_DT_F64, s.data(), iteration, xhat.data(), nullptr,
                            nullptr, status.data(), nullptr);
@@ -382,9 +433,36 @@ static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num
   return LDPC_OK;
 }
 
+// The inputs GFq_LDPC() would decode for a given seed (inspection; host only, needs no GPU)
+extern "C" int GFq_LDPC_experiment(const char *code_filename, int num_reads, double *p_rec_given_sent,
+                                   uint64_t seed, int nframes, int32_t *x, int32_t *s, int32_t *y,
+                                   double *logfna, float *rand_select) {
+  if (!code_filename || !p_rec_given_sent || num_reads <= 0 || nframes < 0 || !x || !logfna) return LDPC_ERR_ARG;
+  ldpc_code *code = nullptr;
+  int rc = ldpc_code_load_alist(code_filename, &code);
+  if (rc) return rc;
+  const int Q = ldpc_code_q(code), n = ldpc_code_n(code), m = ldpc_code_m(code);
+  if (Q < 3) {
+    ldpc_code_free(code);
+    ldpc_set_error("GFq_LDPC_experiment: not a non-binary alist");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  GfqChannel ch;
+  ch.prepare(Q, num_reads, p_rec_given_sent);
+  Rng r{seed};
+  for (int f = 0; f < nframes; f++) {
+    ch.frame(r, n, x + (size_t)f * n, y ? y + (size_t)f * n : nullptr, logfna + (size_t)f * n * Q,
+             rand_select ? rand_select + (size_t)f * n : nullptr);
+    if (s) ldpc_code_syndrome(code, x + (size_t)f * n, s + (size_t)f * m);
+  }
+  ldpc_code_free(code);
+  return LDPC_OK;
+}
+
 // GFq_LDPC(), GFq_LDPC.c:540-655
 extern "C" int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_strs_seek,
                         int num_reads, int decode_mode, double *p_rec_given_sent, double *errors) {
+  SERIALISED;
   (void)num_strs_seek;   // only used by a commented-out fseek in the reference (:587)
   if (errors) errors[0] = errors[1] = 0;
   ldpc_code *code;
@@ -401,6 +479,7 @@ extern "C" int GFq_LDPC_graph(int q, int iteration, int num_trials, int num_strs
                               int rmax_in, const int *col_weight_in, const int *row_weight_in,
                               const int *row_list_col_in, const int *col_list_row_in, const int *col_list_N_in,
                               const int *H_in, double *errors) {
+  SERIALISED;
   (void)num_strs_seek;
   if (errors) errors[0] = errors[1] = 0;
   if (q < 2 || nvar <= 0 || nchk <= 0 || cmax_in <= 0 || rmax_in <= 0 || !row_weight_in || !row_list_col_in || !H_in)
@@ -562,6 +641,7 @@ extern "C" int GFq_LDPC_NTT_experiment(const char *matrix_file, int seed, const 
 
 extern "C" int GFq_LDPC_NTT(int iteration, const char *channel, double level, const char *matrix_file,
                             int32_t *verdict, int32_t *iters) {
+  SERIALISED;
   if (!verdict || iteration < 0) return LDPC_ERR_ARG;
   const int ch = ntt_channel_id(channel);
   if (ch < 0) return LDPC_ERR_ARG;

@@ -111,6 +111,7 @@ def load_library():
     L.test_code_B_float_cw_noise_gen.argtypes = [cp, ip, ip, C.c_double, dp]
     L.test_code_B.argtypes = [ip, ip, C.c_double, cp, dp]
     L.GFq_LDPC.argtypes = [cp, ip, ip, ip, ip, ip, dp, dp]
+    L.GFq_LDPC_experiment.argtypes = [cp, ip, dp, C.c_uint64, ip, vp, vp, vp, vp, vp]
     L.GFq_LDPC_graph.argtypes = [ip, ip, ip, ip, ip, ip, dp, ip, ip, ip, ip, intp, intp, intp, intp, intp, intp, dp]
     L.test_code_B_MSDP.argtypes = [cp, ip, ip, ip, ip, dp, dp]
     L.GFq_LDPC_NTT.argtypes = [ip, cp, C.c_double, cp, vp, vp]

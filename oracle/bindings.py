@@ -206,6 +206,16 @@ class Oracle:
                                          C.byref(it), post.ctypes.data_as(C.c_void_p))
         return dict(rc=rc, x=xh, z=zh, iters=it.value, post=post)
 
+    def gf_channel_draw(self, q, num_reads, conf_normalised, x, rand_select):
+        """channel() :213-231 -> y; conf_normalised as ora_gf_normalise_confusion leaves it."""
+        conf = np.ascontiguousarray(conf_normalised, np.float64)
+        x = np.ascontiguousarray(x, np.int32)
+        rs = np.ascontiguousarray(rand_select, np.float32)
+        y = np.zeros(len(x), np.int32)
+        self.lib.ora_gf_channel_draw.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.ora_gf_channel_draw(q, num_reads, conf.ctypes.data, x.ctypes.data, rs.ctypes.data, len(x), y.ctypes.data)
+        return y
+
     def gf_assign_llr(self, q, num_reads, conf, y):
         conf = np.array(conf, np.float64, order="C").copy()
         self.lib.ora_gf_normalise_confusion(q, num_reads, conf)

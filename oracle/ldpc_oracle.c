@@ -357,9 +357,14 @@ int ora_dec_spa(const ora_code *c, const double *q0, const int *s, int loop_max,
  * then atanh2(1) = inf and inf - inf = NaN), where the reference's double still decodes; the
  * twin therefore evaluates the same two functions without that cancellation (series of
  * -2 atanh(e^-a) above 3, of -expm1(x) above -0.1 and of 2 atanh(e^x) below -3), as the
- * binary32 kernels do (ldpc_amd/csrc/binary_kernels.hip.h).  0, -inf, NaN behave as before. */
+ * binary32 kernels do (ldpc_amd/csrc/binary_kernels.hip.h).  -inf, NaN behave as before; a zero
+ * magnitude is floored at 2^-100, which takes away the reference's log tanh(0) = -inf, -inf - (-inf)
+ * = NaN hazard (:149,:168): binary32 rounding cancels variable sums to exactly 0 on frames where
+ * the reference's double does not. */
 static float logtanh2f(float x) {
-  float a = fabsf(x), t = expf(-a), num;
+  float a = fabsf(x), t, num;
+  if (a < 0x1p-100f) a = 0x1p-100f;
+  t = expf(-a);
   if (a > 3.0f) { float t2 = t * t; return -2.0f * t * (1.0f + t2 * (1.0f / 3.0f + t2 * 0.2f)); }
   num = 1.0f - t;
   if (a < 0.25f)

@@ -415,3 +415,28 @@ void ora_gf_assign_llr(int Q, int num_reads, const double *p_rec_given_sent,
     }
   free(T);
 }
+
+/* channel() (GFq_LDPC.c:213-231), the choice of the read y[i]: rand_select is the
+ * reference's `((float)rand())*100/((float)RAND_MAX)` handed in by the caller (its
+ * rand() stream is seeded from the clock); p_rec_given_sent as for ora_gf_assign_llr.
+ * The reference's first loop (:224-226) has no end test; neither has this one beyond
+ * the table (a column of a normalised matrix always holds a non-zero entry). */
+void ora_gf_channel_draw(int Q, int num_reads, const double *p_rec_given_sent, const int *x,
+                         const float *rand_select_in, int n, int *y)
+{
+  int i, rec_ind;
+  double temp;
+  float rand_select;
+  for (i = 0; i < n; i++) {
+    temp = 0;
+    rec_ind = 0;
+    rand_select = rand_select_in[i];
+    if (!rand_select) {
+      while (rec_ind < Q * num_reads && !p_rec_given_sent[(rec_ind++) * Q + x[i]]);
+    }
+    while (temp < rand_select && rec_ind != Q * num_reads) {
+      temp += 100 * p_rec_given_sent[(rec_ind++) * Q + x[i]];
+    }
+    y[i] = --rec_ind;
+  }
+}

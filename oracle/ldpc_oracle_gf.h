@@ -40,4 +40,8 @@ void ora_gf_assign_llr(int Q, int num_reads, const double *p_rec_given_sent,
 #ifdef __cplusplus
 }
 #endif
+/* channel() :213-231: the read drawn for each symbol from the caller's uniform draws */
+void ora_gf_channel_draw(int Q, int num_reads, const double *p_rec_given_sent, const int *x,
+                         const float *rand_select_in, int n, int *y);
+
 #endif

@@ -97,16 +97,25 @@ def test_minsum_f32(hip, oracle, name, F, p, sigma, it, kind):
         assert same.mean() > 0.9
 
 
-SPA_CASES = [c for c in CASES if c[0] not in ("peg_16000_3_0.9.txt", "32000.2240.3.105.txt")] + [("peg_16000_3_0.9.txt", 6, 0.003, 0.4, 10)]
+# (small_code, n = 12, has weight-2 checks that pass +-L straight through: with equal-magnitude
+# inputs variable sums cancel exactly and the reference's log tanh(0) hazard fires on half the
+# frames at the p of the min-sum cases; a lower p keeps most frames clear of it)
+SPA_CASES = [("small_code.txt", 40, 0.03, 0.9, 8)] + \
+            [c for c in CASES[1:] if c[0] not in ("peg_16000_3_0.9.txt", "32000.2240.3.105.txt")] + \
+            [("peg_16000_3_0.9.txt", 6, 0.003, 0.4, 10)]
 
 
 @pytest.mark.parametrize("name,F,p,sigma,it", SPA_CASES)
 @pytest.mark.parametrize("kind", ["bsc", "awgn"])
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_spa_float(hip, oracle, name, F, p, sigma, it, kind, prec):
-    """libm differs between host and device, so SPA is compared on decoded bits
-    with a margin filter: a frame counts when the oracle's final posteriors all
-    have |sum| > MARGIN (relative tolerance of the LLRs: RTOL)."""
+    """libm differs between host and device in the last ulp, so the sum-product decoders are
+    compared on decoded bits with a margin filter: a frame counts when the oracle's final
+    posteriors hold no NaN (the reference's log tanh(0) = -inf hazard, test_code_B_float.c:149,168,
+    makes a frame's outcome depend on whether a sum cancels exactly) and all have |sum| > MARGIN.
+    On those frames verdict, iteration count and every decoded bit must be EQUAL -- 100 %, no
+    allowance -- and the filter may not drop more than half of the frames.  (Measured in round 2,
+    tools/spa_diag.py: the frames the filter drops agree as well, on every case.)"""
     MARGIN = {"f64": 1e-6, "f32": 1e-2}[prec]
     RTOL = {"f64": 1e-6, "f32": 2e-2}[prec]
     oc = oracle.load(code_path(name))
@@ -122,12 +131,15 @@ def test_spa_float(hip, oracle, name, F, p, sigma, it, kind, prec):
     dec = hip.Decoder(code, alg, max_frames=256, want_llr=True)
     out = dec.decode(llr, s.astype(np.uint8), it, want=("bits", "iters", "synd", "status", "llr"))
     post = ref[4]
-    # NaN (the reference's log tanh(0) = -inf hazard, test_code_B_float.c:149,168) makes a
-    # frame's outcome depend on libm details; +-inf posteriors (saturated tanh) are fine
-    safe = ~np.isnan(post).any(axis=1) & (np.abs(np.where(np.isnan(post), 1.0, post)).min(axis=1) > MARGIN)
-    assert safe.sum() >= max(1, int(0.2 * F)), "margin filter removed too many frames"
+    nan = np.isnan(post).any(axis=1)
+    safe = ~nan & (np.abs(np.where(np.isnan(post), 1.0, post)).min(axis=1) > MARGIN)
+    assert safe.sum() >= 0.5 * F, f"margin filter removed {F - safe.sum()} of {F} frames"
     agree = (out["status"] == ref[3]) & (out["iters"] == ref[1]) & (out["bits"] == ref[0]).all(axis=1)
-    assert agree[safe].mean() >= 0.98, f"spa {prec} {name} {kind}: {agree[safe].mean()}"
+    print(f"spa {prec} {name} {kind}: {agree[safe].sum()}/{safe.sum()} safe frames equal, {agree.sum()}/{F} of all "
+          f"({nan.sum()} with the reference's NaN)")
+    assert agree[safe].all(), f"spa {prec} {name} {kind}: frames {np.where(safe & ~agree)[0]} differ"
+    if prec == "f32":
+        assert not np.isnan(out["llr"][~nan]).any(), "binary32 NaN on a frame where its twin has none"
     # posterior LLRs of frames that ran all iterations on both sides
     both = safe & (ref[3] != 0) & (out["status"] != 0) & agree
     if both.any():
@@ -338,3 +350,63 @@ def test_spa_f32_follows_the_double_reference_past_binary32_saturation(hip, orac
     assert np.array_equal(out["bits"][conv], ref[0][conv])
     assert (np.abs(out["iters"][conv] - ref[1][conv]) <= 2).all()
     assert (out["iters"][conv] == ref[1][conv]).mean() > 0.9
+
+
+def test_high_iteration_early_exit_on_the_32000_code(hip, oracle):
+    """configs[3]: 32000.2240.3.105, loop_max 200, early exit on -- frames at the edge of the
+    min-sum waterfall (AWGN sigma 0.45, found by a seed search with the oracle): the Q8.8
+    oracle stops two frames at 200 iterations, one after 24 and one after 133; the binary64
+    one after 24 and 56.  Q8.8 and binary64 against dec() of test_code_min_sum_B_fixed.c:210-313 /
+    test_code_min_sum_B.c:137-208, bit-exact, with the host's early-exit polling on and off."""
+    name = "32000.2240.3.105.txt"
+    oc = oracle.load(code_path(name))
+    x, s, llr = make_frames(oracle, oc, 4, 0.0, 301, "awgn", sigma=0.45)
+    su = s.astype(np.uint8)
+    q, raw = to_q88(llr)
+    code = hip.Code.from_alist(code_path(name))
+    ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q, s, 200)
+    assert (ref[1] > 50).sum() >= 3 and ((ref[3] == 0) & (ref[1] > 50)).any() and (ref[3] != 0).any()
+    for early in (True, False):
+        dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=64, early_exit=early)
+        check_exact(dec.decode(raw, su, 200), ref, f"q88 32000 x 200 iterations early_exit={early}")
+        dec.close()
+    ref = run_oracle(oracle.dec_minsum, oc, llr, s, 200)
+    assert ((ref[3] == 0) & (ref[1] > 50)).any() and (ref[3] != 0).any()
+    for early in (True, False):
+        dec = hip.Decoder(code, hip.ALG.MINSUM_F64, max_frames=64, early_exit=early)
+        check_exact(dec.decode(llr, su, 200), ref, f"f64 32000 x 200 iterations early_exit={early}")
+        dec.close()
+
+
+def test_spa_f64_on_dvb_s2_across_the_waterfall(hip, oracle, tmp_path):
+    """configs[2]: DVB-S2 rate 1/2 (n = 64800), SPA_F64 = the reference's own arithmetic
+    (test_code_B_float.c:134-199), 50 iterations, three frames each at Eb/N0 0.6, 0.8, 1.0 and
+    1.2 dB (either side of and inside the 0.8-1.0 dB waterfall, sigma^2 = 1 / (2 R 10^(dB/10))) against ora_dec_spa on the
+    padded copy of the alist (the reference-style loader needs the padded dialect).
+    libm differs between glibc and the device library in the last ulp, so frames are compared
+    where the oracle's posteriors hold no NaN (the reference's log tanh(0) hazard): verdict, word
+    and iteration count equal on every such frame that converges; frames that do not converge
+    (below the waterfall) must agree on the verdict and on >= 99.9 % of the bits."""
+    path = str(tmp_path / "padded.alist")
+    hip.alist.normalise_alist(code_path("dvb_H_0.5.txt"), path, padded=True)
+    oc = oracle.load(path)
+    code = hip.Code.from_alist(code_path("dvb_H_0.5.txt"))
+    dec = hip.Decoder(code, hip.ALG.SPA_F64, max_frames=64, want_llr=True)
+    seen_conv = seen_fail = 0
+    for db, seed in ((0.6, 51), (0.8, 53), (1.0, 54), (1.2, 52)):
+        sigma = (1.0 / (2 * 0.5 * 10 ** (db / 10))) ** 0.5
+        x, s, llr = make_frames(oracle, oc, 3, 0.0, seed, "awgn", sigma=sigma)
+        ref = run_oracle(oracle.dec_spa, oc, llr, s, 50)
+        out = dec.decode(llr, s.astype(np.uint8), 50, want=("bits", "iters", "synd", "status", "llr"))
+        ok = ~np.isnan(ref[4]).any(axis=1)
+        print(f"dvb spa_f64 {db} dB: oracle (rc, iters) {list(zip(ref[3], ref[1]))} gpu {list(zip(out['status'], out['iters']))} nan-free {ok}")
+        for f in np.where(ok)[0]:
+            assert out["status"][f] == ref[3][f], (db, f)
+            if ref[3][f] == 0:
+                seen_conv += 1
+                assert out["iters"][f] == ref[1][f] and np.array_equal(out["bits"][f], ref[0][f]), (db, f)
+                assert np.array_equal(out["synd"][f], ref[2][f])
+            else:
+                seen_fail += 1
+                assert (out["bits"][f] != ref[0][f]).mean() <= 1e-3, (db, f)
+    assert seen_conv >= 2 and seen_fail >= 2, (seen_conv, seen_fail)

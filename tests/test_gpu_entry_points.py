@@ -93,6 +93,40 @@ def test_single_frame_entry_points(hip, oracle, entry, alg_fn):
     assert len(seen) >= 2
 
 
+def test_fixed_single_frame_takes_on_grid_llrs_only(hip, oracle):
+    """test_code_min_sum_B of the fixed file (_fixed.c:442-473) hands q0 to dec() untouched, so
+    an off-grid q0 reaches its sums and its iteration-0 test unquantised; the int16 decoder is
+    exact for Q8.8 values only.  On-grid frames (what the reference's bsc() :117-120 makes):
+    equal to the oracle.  Off-grid or out-of-range q0: refused (LDPC_ERR_UNSUPPORTED), not
+    silently rounded -- q0 = -0.001 is bit 1 in the reference and would round to +0 here."""
+    L = hip.load_library()
+    path = code_path("204.33.484.txt")
+    oc = oracle.load(path)
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        p = [0.03, 0.08][trial % 2]
+        x = rng.integers(0, 2, oc.n).astype(np.int32)
+        s = oracle.enc(oc, x)
+        y = (x ^ (rng.random(oc.n) < p)).astype(np.int32)
+        Lq = round(np.log((1 - p) / p) * 256) / 256.0
+        q0 = ((1 - 2 * y) * Lq).astype(np.float64)
+        err = np.zeros(2)
+        assert L.test_code_min_sum_B_fixed(path.encode(), 25, _ip(x), _ip(s), _ip(y), _dp(q0), _dp(err), None) == 0
+        r = oracle.dec_minsum_fixed(oc, q0, s, 25, None, oc.m + 1)
+        assert err.tolist() == ([1.0, 0.0] if r["rc"] else [0.0, float(not np.array_equal(r["bits"], x))])
+    for bad in (-0.001, np.log((1 - 0.03) / 0.03), 127.5, -128.25):
+        q = q0.copy()
+        q[17] = bad
+        err = np.full(2, 7.0)
+        rc = L.test_code_min_sum_B_fixed(path.encode(), 25, _ip(x), _ip(s), _ip(y), _dp(q), _dp(err), None)
+        assert rc == -6 and b"q0[17]" in L.ldpc_last_error() and err.tolist() == [0.0, 0.0]
+    # the oracle shows why: the raw value decides the iteration-0 word, the rounded one would not
+    q = np.full(oc.n, 4.0)
+    q[17] = -0.001
+    r = oracle.dec_minsum_fixed(oc, q, np.zeros(oc.m, np.int32), 0, None, oc.m + 1)
+    assert r["bits"][17] == 1 and oracle.float_to_fix(-0.001) == 0.0
+
+
 def test_monte_carlo_entry_points(hip):
     """*_cw_noise_gen and test_code_B: Monte Carlo over the library's own stream, so the
     check is statistical, as for the reference (srand(time(NULL)))."""

@@ -248,3 +248,68 @@ def test_c_drivers_fail_loudly_without_a_gpu():
     assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout == ""
     r = subprocess.run([exe, "bsc"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and r.stderr.startswith("usage:")
+
+
+@pytest.mark.parametrize("fname,q,num_reads", [("peg_4376_4_0.9_NB.txt", 13, 1), ("peg_4376_4_0.9_NB.txt", 13, 2),
+                                               ("q4.sp.9000.6000.4500.1", 4, 3)])
+def test_gfq_channel_front_end_equals_the_restated_reference(hip, oracle, fname, q, num_reads):
+    """GFq_LDPC()'s channel front-end (GFq_LDPC.c:177-248: column normalisation :548-558,
+    make_p_sent_given_rec_T, channel()'s walk down the column of the sent symbol, assign_llr
+    with the -100 floor) as the library prepares it on the host, against the oracle's
+    restatement, bit for bit: same reads y from the same uniform draws, same log-probabilities
+    (glibc log on both sides).  The reference draws from rand() seeded by the clock, so the
+    draws themselves are an input here (GFq_LDPC_experiment hands them out).  Host only."""
+    import ctypes as C
+    L = hip.load_library()
+    rng = np.random.default_rng(q * 10 + num_reads)
+    R = q * num_reads
+    conf = rng.random((R, q)) ** 4                          # skewed, un-normalised
+    conf[rng.random((R, q)) < 0.3] = 0.0                    # zeros: the -100 floor and the skipped bins
+    conf[np.arange(q) % R, np.arange(q)] += 2.0             # every column keeps mass
+    if num_reads > 1:
+        conf[R - 1] = 0.0                                   # a read value that never occurs (P_y = 0 branch)
+    mine = np.ascontiguousarray(conf, np.float64).copy()
+    code = hip.Code.from_alist(code_path(fname))
+    n, m, F = code.n, code.m, 3
+    x = np.zeros((F, n), np.int32); s = np.zeros((F, m), np.int32); y = np.zeros((F, n), np.int32)
+    lf = np.zeros((F, n, q), np.float64); sel = np.zeros((F, n), np.float32)
+    rc = L.GFq_LDPC_experiment(code_path(fname).encode(), num_reads, mine.ctypes.data_as(C.POINTER(C.c_double)),
+                               987654321, F, x.ctypes.data, s.ctypes.data, y.ctypes.data, lf.ctypes.data,
+                               sel.ctypes.data)
+    assert rc == 0, L.ldpc_last_error()
+    theirs = np.ascontiguousarray(conf, np.float64).copy()
+    oracle.lib.ora_gf_normalise_confusion(q, num_reads, theirs)
+    assert np.array_equal(mine, theirs)                     # normalised in place, :548-558
+    oc = oracle.load(code_path(fname))
+    assert ((x >= 0) & (x < q)).all() and len(np.unique(x)) == q
+    assert (sel >= 0).all() and (sel <= 100).all() and sel.std() > 20
+    for f in range(F):
+        assert np.array_equal(s[f], oracle.gf_enc(oc, q, x[f]))
+        yo = oracle.gf_channel_draw(q, num_reads, theirs, x[f], sel[f])
+        assert np.array_equal(y[f], yo)
+        lo = oracle.gf_assign_llr(q, num_reads, conf, yo)    # [q][n]; normalises its own copy
+        assert np.array_equal(lf[f], lo.T)
+    assert (lf == -100).any() and (y != x).any()
+    if num_reads > 1:
+        assert (y < R - 1).all()                            # the impossible read is never drawn
+
+
+def test_malformed_csr_is_refused(hip):
+    """ldpc_code_from_csr (the WD-farm graph-passing boundary, WD_farm/GFq_LDPC.c:477) validates
+    the caller's arrays before anything is read through them: row_ptr must start at 0 and be
+    monotone, columns in range, no variable twice in a row (the slot tables match edges by
+    position: a duplicate would silently decode another graph)."""
+    ok = dict(n=6, m=3, row_ptr=[0, 3, 5, 8], col_idx=[0, 1, 2, 2, 3, 3, 4, 5])
+    code = hip.Code.from_csr(**ok)
+    assert (code.n, code.m, code.E, code.rmax, code.cmax) == (6, 3, 8, 3, 2)
+    bad = [dict(ok, row_ptr=[1, 3, 5, 8]),                      # leading edges that belong to no check
+           dict(ok, row_ptr=[0, 5, 3, 8]),                      # not monotone
+           dict(ok, col_idx=[0, 1, 1, 2, 3, 3, 4, 5]),          # variable 1 twice in row 0
+           dict(ok, col_idx=[0, 1, 2, 2, 3, 3, 4, 6]),          # column out of range
+           dict(ok, col_idx=[0, 1, 2, 2, 3, 3, 4, -1])]
+    for kw in bad:
+        with pytest.raises(hip.LdpcError) as e:
+            hip.Code.from_csr(**kw)
+        assert e.value.code == -1, kw
+    with pytest.raises(hip.LdpcError):                          # GF coefficient out of range
+        hip.Code.from_csr(4, 2, [0, 2, 4], [0, 1, 2, 3], hval=[1, 2, 3, 4], q=4)
