@@ -96,8 +96,9 @@ inline FusedKern fused_reg_lookup(int cpt, int r2, int sh) {
   return k;
 }
 
-// timing experiments only (results wrong when non-zero): 1 no adds, 2 no reads, 4 no barriers
-// inside the iteration loop, 8 conflict-free read addresses, 16 conflict-free add addresses
+// timing experiments only (results wrong when non-zero; tools/probes/build_ablate.sh): 1 no LDS
+// adds in phase B (the arithmetic stays), 2 no LDS reads in phase A (the arithmetic stays, on
+// register values), 4 no barriers inside the iteration loop (and no exit test)
 #ifndef LDPC_FUSED_ABLATE
 #define LDPC_FUSED_ABLATE 0
 #endif
@@ -460,6 +461,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             for (int j = 0; j < CH; j++) {
               const int k = kc + j;
               if (k >= RM) continue;               // (compile time: last chunk of an RM that CH does not divide)
+              if (LDPC_FUSED_ABLATE & 2) S[r][j] = (int)(unsigned)(unsigned long)((k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]));
+              else
               S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
             }
 #pragma unroll
@@ -567,6 +570,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             nrot[k / 32] = fq_shl1(nrot[k / 32]);
             prot[k / 32] = fq_shl1(prot[k / 32]);
             const int delta = (int)(cn - co);
+            if (LDPC_FUSED_ABLATE & 1) asm volatile("" ::"v"(delta), "v"(dst));
+            else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
           }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Timing variants of the PEG-16000 fused kernel (results wrong): build_ablate/libldpc_hip_abl<N>.so
+# with -DLDPC_FUSED_ABLATE=N in the translation unit that holds fused_q88_reg_kernel<2,16,...>.
+set -e
+cd "$(dirname "$0")/../../ldpc_amd/csrc"
+mkdir -p ../../build_ablate
+for N in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc -DFQ_PART=2 -DLDPC_FUSED_ABLATE=$N -c fused_inst.hip -o ../../build_ablate/fused_inst_2_abl$N.o &
+done
+wait
+for N in "$@"; do
+  OBJS=$(ls build/*.o | grep -v fused_inst_2.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ablate/libldpc_hip_abl$N.so $OBJS ../../build_ablate/fused_inst_2_abl$N.o
+done
+ls -la ../../build_ablate/*.so
