@@ -60,6 +60,9 @@ struct FfArgs {
   // register-cached kernel only
   const uint16_t *vtabT;   // [VPT*CM][block]  (check << 5) | shift of its sign bit, per (thread, variable, edge)
   const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
+  // QG kernels (frames whose q0 does not fit beside the sums): the channel LLRs in placed order,
+  // one row of var_words values per workgroup, in global memory (L2 / Infinity Cache resident)
+  void *q0g;
 };
 
 #ifndef FF_ONEHOT
@@ -70,15 +73,20 @@ struct FfArgs {
 
 template <int NW> struct FfSgw { static constexpr int value = NW == 1 ? 2 : 4; };
 
-template <typename T, int CPT, int NW>
+// QG: the frame's channel LLRs stay in global memory (a.q0g, placed order, written once per frame
+// and re-read by every variable pass) instead of LDS, and the check records are packed
+// (sign words, then one byte per check for the slot of min1): binary64 sums of a 16 000-variable
+// frame are 128 KB, which leaves room for the records but not for a second array of that size.
+template <typename T, int CPT, int NW, bool QG = false>
 __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ff_lds[];
-  constexpr int SGW = FfSgw<NW>::value;        // words of sign/arg state per check
+  constexpr int SGW = QG ? NW : FfSgw<NW>::value;   // words of sign (/arg) state per check
   T *sumL = (T *)ff_lds;
-  T *q0L = sumL + a.words;
-  T *magL = q0L + a.var_words;                 // [m + 1][2]  min1, min2
-  uint32_t *sgL = (uint32_t *)(magL + 2 * (a.m + 1));   // [m + 1][SGW]  sign words, slot of min1
-  int *frame_slot = (int *)(sgL + SGW * (a.m + 1));
+  T *q0L = QG ? (T *)a.q0g + (size_t)blockIdx.x * a.var_words : sumL + a.words;
+  T *magL = QG ? sumL + a.words : q0L + a.var_words;                 // [m + 1][2]  min1, min2
+  uint32_t *sgL = (uint32_t *)(magL + 2 * (a.m + 1));   // [m + 1][SGW]  sign words (, slot of min1)
+  uint8_t *argL = (uint8_t *)(sgL + SGW * (a.m + 1));   // QG: [m + 1] slot of min1
+  int *frame_slot = QG ? (int *)(((size_t)(argL + a.m + 1) + 3) & ~(size_t)3) : (int *)(sgL + SGW * (a.m + 1));
   const int tid = threadIdx.x, B = blockDim.x;
   const T BIG = (T)1e30;
 
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
     magL[2 * a.m] = (T)0; magL[2 * a.m + 1] = (T)0;
 #pragma unroll
     for (int w = 0; w < NW; w++) sgL[SGW * a.m + w] = 1u;
-    sgL[SGW * a.m + NW] = 1u;
+    if (QG) argL[a.m] = 1; else sgL[SGW * a.m + NW] = 1u;
     *frame_slot = atomicAdd(a.counter, 1);
   }
   __syncthreads();
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
             osg[r][w] = (tot & 1u) ? (sg[w] ^ real[r][w]) : sg[w];
             sgL[SGW * j + w] = osg[r][w];
           }
-          sgL[SGW * j + NW] = arg;
+          if (QG) argL[j] = (uint8_t)arg; else sgL[SGW * j + NW] = arg;
           om1[r] = m1; om2[r] = m2; oarg[r] = arg;
         }
       }
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
           const uint32_t e = a.vtab[(size_t)kk * a.var_words + w];
           const int j = (int)(e >> 8), p = (int)(e & 0xffu);
           const uint32_t sw = sgL[SGW * j + (NW == 1 ? 0 : (p >> 5))];
-          const uint32_t arg = sgL[SGW * j + NW];
+          const uint32_t arg = QG ? (uint32_t)argL[j] : sgL[SGW * j + NW];
           const T mg = magL[2 * j + (arg == (uint32_t)p ? 1 : 0)];
           sum = sum + (((sw >> (p & 31)) & 1u) ? -mg : mg);
         }
@@ -536,15 +544,15 @@ namespace {
 
 typedef void (*FfKern)(FfArgs);
 
-template <typename T, int NW>
+template <typename T, int NW, bool QG = false>
 FfKern ff_pick(int cpt) {
   switch (cpt) {
-    case 1: return fused_ms_kernel<T, 1, NW>;
-    case 2: return fused_ms_kernel<T, 2, NW>;
-    case 3: return fused_ms_kernel<T, 3, NW>;
-    case 4: return fused_ms_kernel<T, 4, NW>;
-    case 5: case 6: return fused_ms_kernel<T, 6, NW>;
-    case 7: case 8: return fused_ms_kernel<T, 8, NW>;
+    case 1: return fused_ms_kernel<T, 1, NW, QG>;
+    case 2: return fused_ms_kernel<T, 2, NW, QG>;
+    case 3: return fused_ms_kernel<T, 3, NW, QG>;
+    case 4: return fused_ms_kernel<T, 4, NW, QG>;
+    case 5: case 6: return fused_ms_kernel<T, 6, NW, QG>;
+    case 7: case 8: return fused_ms_kernel<T, 8, NW, QG>;
   }
   return nullptr;
 }
@@ -573,12 +581,20 @@ struct FusedFloatEngine : Engine {
     const int sgw = nw == 1 ? 2 : 4;
     return sizeof(T) * ((size_t)words + var_words + 2 * (size_t)(m + 1)) + 4 * (size_t)sgw * (m + 1) + 16;
   }
+  // the QG kernels: no q0 in LDS, packed records
+  static size_t lds_bytes_qg(int words, int m, int nw) {
+    return sizeof(T) * ((size_t)words + 2 * (size_t)(m + 1)) + 4 * (size_t)nw * (m + 1) + (size_t)(m + 1) + 24;
+  }
+  bool qg = false;
+  DevBuf d_q0g;
+  void *ws_q0g = nullptr;
   // (the schedule may leave a few words of slack per bank: n + 64 bounds var_words closely enough
   // for a first test; init() checks the real figure)
   static bool fits(const ldpc_code &c) {
     if (c.q != 2 || c.n > 65000 || c.rmax > 64 || c.rmax < 1 || c.cmax > 32 || c.m > 8192) return false;
     const int nw = (2 * ((c.rmax + 1) / 2) + 31) / 32;
-    return lds_bytes(c.n + 64 + FF_NDUMMY, c.n + 64, c.m, nw) + 1024 <= 160 * 1024;
+    return lds_bytes(c.n + 64 + FF_NDUMMY, c.n + 64, c.m, nw) + 1024 <= 160 * 1024 ||
+           lds_bytes_qg(c.n + 64 + FF_NDUMMY, c.m, nw) + 256 <= 160 * 1024;
   }
   size_t llr_elems_per_frame() const override { return (size_t)n; }
 
@@ -687,7 +703,13 @@ struct FusedFloatEngine : Engine {
     }
     rounds = sched.rounds;
     lds = lds_bytes(sched.words, sched.var_words, m, NW);
+    qg = false;
     if (lds + 1024 > 160 * 1024) {
+      // q0 in global memory, packed records (QG kernels)
+      lds = lds_bytes_qg(sched.words, m, NW);
+      qg = true;
+    }
+    if (lds + 256 > 160 * 1024) {
       ldpc_set_error("fused min-sum: frame does not fit in LDS");
       return LDPC_ERR_UNSUPPORTED;
     }
@@ -699,7 +721,8 @@ struct FusedFloatEngine : Engine {
       if (g >= 1 && (size_t)g * (lds + 512) <= 160 * 1024) wg_per_cu = g;
     }
     if (!use_reg)
-    kern = NW == 1 ? ff_pick<T, 1>(rounds) : ff_pick<T, 2>(rounds);
+    kern = qg ? (NW == 1 ? ff_pick<T, 1, true>(rounds) : ff_pick<T, 2, true>(rounds))
+              : (NW == 1 ? ff_pick<T, 1>(rounds) : ff_pick<T, 2>(rounds));
     if (!kern) { ldpc_set_error("no fused min-sum kernel for this code shape"); return LDPC_ERR_UNSUPPORTED; }
 
     // which slots hold edges (bit k of word k / 32), and where each edge of each variable sits
@@ -727,6 +750,7 @@ struct FusedFloatEngine : Engine {
     if ((rc = d_vtab.ensure(vtab.size() * 4))) return rc;
     if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
     if ((rc = d_counter.ensure(256))) return rc;
+    if (qg && (rc = d_q0g.ensure((size_t)num_cu * wg_per_cu * sched.var_words * sizeof(T)))) return rc;
     HIPCHK(hipMemcpy(d_colT.p, sched.colT.data(), sched.colT.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_realT.p, realT.data(), realT.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_vtab.p, vtab.data(), vtab.size() * 4, hipMemcpyHostToDevice));
@@ -774,6 +798,7 @@ struct FusedFloatEngine : Engine {
     a.llr = llr; a.dt = dt; a.synd = sy;
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
     a.counter = counter;
+    a.q0g = ws_q0g ? ws_q0g : d_q0g.p;
     a.vtabT = d_vtabT.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
@@ -792,9 +817,23 @@ struct FusedFloatEngine : Engine {
                 uint8_t *bits, int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out,
                 hipStream_t st) override {
     if (!ws || ws_bytes < 256) { ldpc_set_error("scratch too small for the frame queue head"); return LDPC_ERR_ARG; }
+    if (qg) {
+      // one placed copy of q0 per workgroup in flight
+      long grid = (long)num_cu * wg_per_cu;
+      if (grid > nframes) grid = nframes;
+      const size_t need = 256 + (size_t)grid * sched.var_words * sizeof(T);
+      if (need > ws_bytes) {
+        ldpc_set_error("allocation-free decode: " + std::to_string(nframes) + " frames of this code need " +
+                       std::to_string(need) + " bytes of channel-LLR workspace, the static scratch holds " +
+                       std::to_string(ws_bytes) + " (use ldpc_decode_batch_device, or fewer frames per call)");
+        return LDPC_ERR_ARG;
+      }
+      ws_q0g = (char *)ws + 256;
+    }
     ws_counter = (int *)ws;
     const int rc = decode(nframes, llr, dt, sy, max_iter, bits, iters_out, sout, status, llr_out, st);
     ws_counter = nullptr;
+    ws_q0g = nullptr;
     return rc;
   }
 };
