@@ -213,6 +213,14 @@ int ldpc_code_lds_schedule_stats(const ldpc_code *c, int block, int optimise, in
  * check still visiting exactly its variables)}.  Host only; needs no GPU. */
 int ldpc_code_vpass_place_stats(const ldpc_code *c, int block, int64_t *stats);
 
+/* Diagnostics of the GF(2^p) decoder's compact tables (no counterpart in the reference): the
+ * kernels evaluate Fexp / Flog (GFq_LDPC_NTT.c:196-247) from an 80 KiB LDS image instead of the
+ * reference's 12 MiB of tables; this replays their arithmetic on the host against every entry of
+ * both full tables.  stats[4] = {Fexp entries that differ (must be 0), Flog entries that differ
+ * without having been handed back to the full table (must be 0), Flog entries handed back,
+ * Flog entries kept verbatim}.  Returns the number of differing entries.  Host only. */
+int64_t ldpc_wht_tables_selfcheck(int64_t *stats);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only
  * instrumentation is clock() around the trial loop, test_code_B.c:334,354-356).
  * With profiling enabled every launch of the decoding kernels is bracketed by a

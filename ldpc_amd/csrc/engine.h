@@ -146,6 +146,19 @@ struct Engine {
 // host-built lookup tables (tables.cpp)
 void ldpc_build_spa_tables(std::vector<int32_t> &flogtanh, std::vector<int32_t> &fgallag);
 void ldpc_build_wht_tables(std::vector<int32_t> &flog, std::vector<uint32_t> &fexp);
+// compact exact forms of the WHT tables (tables.cpp)
+constexpr int kWhtFrac = 1 << 14;   // fraction cells of fexp
+constexpr int kWhtSeg = 512;        // log2 segments of flog
+constexpr int kWhtSmall = 2048;     // flog entries kept verbatim (the last entry that is not round(16384 log2 i) - 14 * 16384 is 1955)
+struct WhtCompact {
+  std::vector<uint32_t> xexp;       // [kWhtFrac]
+  std::vector<float> lseg;          // [kWhtSeg][4]: c0 fraction, c1, c2, unused
+  std::vector<int32_t> lsegi;       // [kWhtSeg]: c0 integer part
+};
+void ldpc_build_wht_compact(WhtCompact &c);
+uint32_t ldpc_wht_fexp_compact(const WhtCompact &c, int x);
+int ldpc_wht_flog_compact(const WhtCompact &c, int i, bool *defer);
+long ldpc_wht_compact_selfcheck(long stats[4]);
 void ldpc_gf_tables_host(int q, int *logq, int *expq);
 int ldpc_gf_mul_host(int q, int a, int b);
 

@@ -40,7 +40,12 @@ struct GGraph {
 struct WTab {
   const int32_t *flog;    // [2^20]
   const uint32_t *fexp;   // centre of a [2^21] table: fexp[i], i in [-2^20, 2^20)
+  const uint32_t *image;  // compact exact forms of both (tables.cpp), W_IMAGE_WORDS words: copied to LDS
 };
+// LDS image of the compact tables: xexp[16384] | flog[0..2047] | seg[512] of {c0 fraction, c1, c2, c0 integer}
+constexpr int W_IMG_XEXP = 0, W_IMG_SMALL = kWhtFrac, W_IMG_SEG = kWhtFrac + kWhtSmall;
+constexpr int W_IMAGE_WORDS = kWhtFrac + kWhtSmall + 4 * kWhtSeg;   // 80 KiB
+typedef float w_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int gf_sub(const GGraph &g, int a, int b) {
   return g.pow2 ? (a ^ b) : (a - b + 2 * g.Q) % g.Q;
@@ -63,6 +68,44 @@ __device__ __forceinline__ int w_fexp(const WTab &t, int x) {
   x = x > W_LEVELS - 1 ? W_LEVELS - 1 : x;
   return (int)t.fexp[x];
 }
+// The same two functions from the compact tables in LDS (img): bit-identical for every argument
+// (ldpc_wht_compact_selfcheck replays this arithmetic over both full tables).
+__device__ __forceinline__ int w_fexp_c(const uint32_t *img, int x) {
+  x = x < -W_LEVELS ? -W_LEVELS : x;
+  x = x > W_LEVELS - 1 ? W_LEVELS - 1 : x;
+  if (x > 17 * kWhtFrac) return (int)(1u << 31);
+  const int e = x >> W_DECI, fr = x & (kWhtFrac - 1);
+  const int sh = 18 - e;                                   // >= 1
+  const unsigned long long Y = (1ull << 32) | img[W_IMG_XEXP + fr];
+  const unsigned v = (unsigned)((Y + (1ull << ((sh - 1) & 63))) >> (sh & 63));
+  return sh >= 34 ? 0 : (int)v;
+}
+__device__ __forceinline__ int w_flog_c(const uint32_t *img, const WTab &t, int x) {
+  if (x <= 0) return -W_FMUL * 14;
+  int i = 0;
+  while (x >= W_LEVELS) { x >>= 1; i++; }
+  int v;
+  if (x < kWhtSmall) {
+    v = (int)img[W_IMG_SMALL + x];
+  } else {
+    const int e = 31 - __clz(x);
+    const int r = x - (1 << e), sh = e - 9;
+    const int h = r >> sh, lo = r & ((1 << sh) - 1);
+    const float u = ldexpf((float)lo, -e) - 0x1p-10f;
+    const w_f4 q = *(const w_f4 *)(img + W_IMG_SEG + 4 * h);
+    const float w = fmaf(u, fmaf(u, q.z, q.y), q.x);
+    const float fl = floorf(w + 0.5f);
+    if (fabsf(w - fl) > 0.5f - 1e-4f) v = t.flog[x];       // too close to a rounding boundary (2e-4 of the arguments): the full table decides
+    else v = __float_as_int(q.w) + W_FMUL * (e - 14) + (int)fl;
+  }
+  return v + (i << W_DECI);
+}
+__device__ __forceinline__ void w_load_image(uint32_t *img, const WTab &t) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  for (int i = threadIdx.x; i < W_IMAGE_WORDS / 4; i += blockDim.x) ((u4 *)img)[i] = ((const u4 *)t.image)[i];
+  __syncthreads();
+}
+
 // ntt(), :118-135, one value per lane: stage b pairs lanes a and a ^ (1<<b)
 __device__ __forceinline__ int wht_lanes(int y, int a, int log2q) {
   for (int b = 0; b < log2q; b++) {
@@ -226,6 +269,117 @@ __global__ __launch_bounds__(256) void gf2p_vn_kernel(GGraph g, WTab tab, int nf
     if (sum <= 0) sum = g.Q;
     q -= w_flog(tab, sum);
     if (live) qa[off] = q;
+  }
+}
+
+// The two kernels above with the compact tables in LDS (80 KiB per workgroup, loaded once) and
+// persistent workgroups: every Fexp is one LDS read and a 64-bit shift, every Flog an LDS read
+// and two fused multiply-adds, instead of a gather of 64 separate L2 lines per wavefront from
+// 12 MiB of tables (what bounded the kernels above: profiles/r02_gf4_wht_counters.txt).
+// fq packs Flog (<< 1) with the sign bit: [waves][dc][64] ints of LDS behind the image.
+template <int PF>   // PF > 0: row weights <= PF, all of a check's inputs are loaded before any is used
+__global__ __launch_bounds__(1024) void gf2p_cn_lds_kernel(GGraph g, WTab tab, int nfg, int dcmax,
+                                                           const int *__restrict__ qa, int *__restrict__ ra,
+                                                           const uint8_t *__restrict__ synd) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t w_lds[];
+  w_load_image(w_lds, tab);
+  const Lane L = lane_of(g);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int *fq = (int *)(w_lds + W_IMAGE_WORDS) + (size_t)wave * dcmax * 64;
+  const bool live = L.l < g.G * g.Q;
+  const int half = g.log2q / 2;
+  const long items = (long)g.m * nfg;
+  for (long item = (long)blockIdx.x * nw + wave; item < items; item += (long)gridDim.x * nw) {
+    const int j = (int)(item / nfg), fg = (int)(item - (long)j * nfg);
+    const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
+    const int f = fg * g.G + L.g;
+    const int z = (synd && L.active) ? synd[(size_t)j * g.Fpad + f] : 0;
+    int logprod = 0, sgnsum = 0;
+    int pre[PF > 0 ? PF : 1];
+    if constexpr (PF > 0) {
+#pragma unroll
+      for (int k = 0; k < PF; k++)
+        pre[k] = (k < dc && live) ? qa[((size_t)(p0 + k) * g.Fpad + (size_t)fg * g.G) * g.Q + L.l] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < (PF > 0 ? PF : dc); k++) {
+      if (PF > 0 && k >= dc) break;
+      const int e = p0 + k;
+      const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * g.Q + L.l;
+      const int x = w_fexp_c(w_lds, PF > 0 ? pre[k] : (live ? qa[off] : 0));
+      int y = __shfl(x, L.base + g.mul[L.a * g.Q + g.hinv[e]]);
+      y = wht_lanes(y, L.a, g.log2q);
+      int neg = 0;
+      if (y < 0) { y = -y; neg = 1; }
+      sgnsum ^= neg;
+      y = (y + (1 << (half - 1))) >> half;
+      const int lg = w_flog_c(w_lds, tab, y);
+      fq[k * 64 + L.l] = lg * 2 + neg;
+      logprod += lg;
+    }
+    for (int k = 0; k < dc; k++) {
+      const int e = p0 + k;
+      const size_t off = ((size_t)e * g.Fpad + (size_t)fg * g.G) * g.Q + L.l;
+      const int pk = fq[k * 64 + L.l];
+      int r = w_fexp_c(w_lds, logprod - (pk >> 1) + g.log2q * W_FMUL);
+      if ((pk & 1) != sgnsum) r = -r;
+      r = wht_lanes(r, L.a, g.log2q);
+      const int t = __shfl(r, L.base + (z ^ g.mul[L.a * g.Q + g.hval[e]]));
+      if (live) ra[off] = w_flog_c(w_lds, tab, t);
+    }
+  }
+}
+
+template <int PF>   // PF > 0: column weights <= PF, a variable's messages are loaded once, up front
+__global__ __launch_bounds__(1024) void gf2p_vn_lds_kernel(GGraph g, WTab tab, int nfg, const int *__restrict__ fna,
+                                                           const int *__restrict__ ra, int *__restrict__ qa,
+                                                           uint8_t *__restrict__ xhat,
+                                                           const uint8_t *__restrict__ frozen) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t w_lds[];
+  w_load_image(w_lds, tab);
+  const Lane L = lane_of(g);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const bool live = L.l < g.G * g.Q;
+  const long items = (long)g.n * nfg;
+  for (long item = (long)blockIdx.x * nw + wave; item < items; item += (long)gridDim.x * nw) {
+    const int i = (int)(item / nfg), fg = (int)(item - (long)i * nfg);
+    const int p0 = g.col_ptr[i], dv = g.col_ptr[i + 1] - p0;
+    const size_t fo = (size_t)fg * g.G * g.Q + L.l;
+    int logprod = live ? fna[(size_t)i * g.Fpad * g.Q + fo] : 0;
+    int pre[PF > 0 ? PF : 1], pe[PF > 0 ? PF : 1];
+    if constexpr (PF > 0) {
+#pragma unroll
+      for (int k = 0; k < PF; k++) {
+        pe[k] = k < dv ? g.edge_of[p0 + k] : 0;
+        pre[k] = (k < dv && live) ? ra[(size_t)pe[k] * g.Fpad * g.Q + fo] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < PF; k++) logprod += pre[k];
+    } else {
+      for (int k = 0; k < dv; k++) {
+        const int e = g.edge_of[p0 + k];
+        logprod += live ? ra[(size_t)e * g.Fpad * g.Q + fo] : 0;
+      }
+    }
+    int maxp = -(1 << 30), arg = -1;
+    for (int t = 0; t < g.Q; t++) {
+      const int v = __shfl(logprod, L.base + t);
+      if (v > maxp) { maxp = v; arg = t; }
+    }
+    const int f = fg * g.G + L.g;
+    if (live && L.a == 0 && !frozen[f]) xhat[(size_t)i * g.Fpad + f] = (uint8_t)arg;
+#pragma unroll
+    for (int k = 0; k < (PF > 0 ? PF : dv); k++) {
+      if (PF > 0 && k >= dv) break;
+      const int e = PF > 0 ? pe[k] : g.edge_of[p0 + k];
+      const size_t off = (size_t)e * g.Fpad * g.Q + fo;
+      int q = logprod - (PF > 0 ? pre[k] : (live ? ra[off] : 0));
+      int sum = w_fexp_c(w_lds, q);
+      for (int b = 0; b < g.log2q; b++) sum += __shfl_xor(sum, 1 << b);
+      if (sum <= 0) sum = g.Q;
+      q -= w_flog_c(w_lds, tab, sum);
+      if (live) qa[off] = q;
+    }
   }
 }
 
@@ -525,7 +679,11 @@ struct GfEngine : Engine {
   int G = 1, Fpad_max = 0;
   GGraph g{};
   WTab tab{};
-  DevBuf d_row_ptr, d_col_idx, d_hval, d_hinv, d_col_ptr, d_edge_of, d_mul, d_flog, d_fexp;
+  DevBuf d_row_ptr, d_col_idx, d_hval, d_hinv, d_col_ptr, d_edge_of, d_mul, d_flog, d_fexp, d_wimg;
+  bool lds_tables = false;   // GF2P_WHT: compact tables in LDS (gf2p_*_lds_kernel)
+  void (*cn_lds_kern)(GGraph, WTab, int, int, const int *, int *, const uint8_t *) = nullptr;
+  void (*vn_lds_kern)(GGraph, WTab, int, const int *, const int *, int *, uint8_t *, const uint8_t *) = nullptr;
+  int cn_waves = 0, num_cu = 256;
   DevBuf fna, qa, ra, xhat, zhat, synd, st_i32, st_frozen, remaining;
   int32_t *h_remaining = nullptr;
   int remaining_cap = 0;
@@ -561,6 +719,11 @@ struct GfEngine : Engine {
   int init(const ldpc_code &c, const ldpc_opts &o) override {
     opts = o;
     n = c.n; m = c.m; E = c.E(); Q = c.q; rmax = c.rmax;
+    {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, o.device));
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     const bool pow2 = (Q & (Q - 1)) == 0;
     int log2q = 0;
     while ((1 << log2q) < Q) log2q++;
@@ -618,6 +781,32 @@ struct GfEngine : Engine {
       if ((rc = upload(d_fexp, fe))) return rc;
       tab.flog = d_flog.as<int32_t>();
       tab.fexp = d_fexp.as<uint32_t>() + W_LEVELS;
+      // compact forms, kept in LDS by the *_lds kernels
+      WhtCompact wc;
+      ldpc_build_wht_compact(wc);
+      std::vector<int32_t> img((size_t)W_IMAGE_WORDS, 0);
+      memcpy(&img[W_IMG_XEXP], wc.xexp.data(), sizeof(uint32_t) * kWhtFrac);
+      memcpy(&img[W_IMG_SMALL], fl.data(), sizeof(int32_t) * kWhtSmall);
+      for (int h = 0; h < kWhtSeg; h++) {
+        memcpy(&img[W_IMG_SEG + 4 * h], &wc.lseg[(size_t)h * 4], sizeof(float) * 3);
+        img[W_IMG_SEG + 4 * h + 3] = wc.lsegi[h];
+      }
+      if ((rc = upload(d_wimg, img))) return rc;
+      tab.image = d_wimg.as<uint32_t>();
+      // workgroup shape of the LDS-table kernels: as many wavefronts as the per-wave rows leave room for
+      int env_c = 1;
+      if (const char *e = getenv("LDPC_HIP_GF_LDS_TABLES")) env_c = atoi(e);
+      const size_t img_bytes = (size_t)W_IMAGE_WORDS * 4, row_bytes = (size_t)std::max(1, rmax) * 64 * 4;
+      cn_waves = (int)std::min<size_t>(16, (158 * 1024 - img_bytes) / row_bytes);
+      lds_tables = env_c != 0 && cn_waves >= 4;
+      if (lds_tables) {
+        cn_lds_kern = rmax <= 4 ? gf2p_cn_lds_kernel<4> : rmax <= 8 ? gf2p_cn_lds_kernel<8> : gf2p_cn_lds_kernel<0>;
+        vn_lds_kern = c.cmax <= 4 ? gf2p_vn_lds_kernel<4> : c.cmax <= 8 ? gf2p_vn_lds_kernel<8> : gf2p_vn_lds_kernel<0>;
+        HIPCHK(hipFuncSetAttribute((const void *)cn_lds_kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(img_bytes + cn_waves * row_bytes)));
+        HIPCHK(hipFuncSetAttribute((const void *)vn_lds_kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)img_bytes));
+      }
     }
     const size_t per = (size_t)Fpad_max * Q * sizeof(T);
     if ((rc = fna.ensure(per * n))) return rc;
@@ -728,10 +917,17 @@ struct GfEngine : Engine {
     (void)literal_cn;
     for (int t = 0; t < max_iter; t++) {
       prof_begin(K_CN, st);
-      if constexpr (WHT)
-        hipLaunchKernelGGL(gf2p_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, tab, nfg,
-                           qa.as<int>(), ra.as<int>(), sy);
-      else if (literal_cn)
+      if constexpr (WHT) {
+        if (lds_tables) {
+          const size_t lb = (size_t)W_IMAGE_WORDS * 4 + (size_t)cn_waves * std::max(1, rmax) * 64 * 4;
+          const size_t want = ((size_t)m * nfg + cn_waves - 1) / cn_waves;
+          hipLaunchKernelGGL(cn_lds_kern, dim3((unsigned)std::min<size_t>(want, (size_t)num_cu)), dim3(cn_waves * 64),
+                             lb, st, gg, tab, nfg, std::max(1, rmax), qa.as<int>(), ra.as<int>(), sy);
+        } else {
+          hipLaunchKernelGGL(gf2p_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, tab, nfg,
+                             qa.as<int>(), ra.as<int>(), sy);
+        }
+      } else if (literal_cn)
         hipLaunchKernelGGL(gfq_cn_kernel, dim3((unsigned)((size_t)m * nfg)), dim3(64), lds, st, gg, nfg,
                            qa.as<double>(), ra.as<double>(), sy);
       else if (rmax > 8) {   // heavy checks: rho parked in ra, three LDS rows
@@ -748,10 +944,17 @@ struct GfEngine : Engine {
       LAUNCHCHK("gf cn kernel");
       prof_end(st);
       prof_begin(K_VN, st);
-      if constexpr (WHT)
-        hipLaunchKernelGGL(gf2p_vn_kernel, dim3(vn_blocks), dim3(256), 0, st, gg, tab, nfg, fna.as<int>(),
-                           ra.as<int>(), qa.as<int>(), xhat.as<uint8_t>(), fs.frozen);
-      else
+      if constexpr (WHT) {
+        if (lds_tables) {
+          const size_t want = ((size_t)n * nfg + 15) / 16;
+          hipLaunchKernelGGL(vn_lds_kern, dim3((unsigned)std::min<size_t>(want, (size_t)num_cu)), dim3(1024),
+                             (size_t)W_IMAGE_WORDS * 4, st, gg, tab, nfg, fna.as<int>(), ra.as<int>(), qa.as<int>(),
+                             xhat.as<uint8_t>(), fs.frozen);
+        } else {
+          hipLaunchKernelGGL(gf2p_vn_kernel, dim3(vn_blocks), dim3(256), 0, st, gg, tab, nfg, fna.as<int>(),
+                             ra.as<int>(), qa.as<int>(), xhat.as<uint8_t>(), fs.frozen);
+        }
+      } else
         hipLaunchKernelGGL(gfq_vn_kernel, dim3(vn_blocks), dim3(256), 0, st, gg, nfg, fna.as<double>(),
                            ra.as<double>(), qa.as<double>(), xhat.as<uint8_t>(), fs.frozen);
       LAUNCHCHK("gf vn kernel");

@@ -76,6 +76,91 @@ void ldpc_build_wht_tables(std::vector<int32_t> &flog, std::vector<uint32_t> &fe
   }
 }
 
+// --- compact, exact forms of the two tables (round 2) ---
+// The 12 MiB of tables are gathered four times per edge and symbol; every gather of a wavefront
+// is 64 separate L2 requests, and that request rate bounded the GF(2^p) kernels (profiles/
+// r02_gf4_wht_counters.txt).  Both tables have structure the kernels can use from LDS instead:
+//
+//  * fexp[i] is, for every one of its 2^21 entries, the rounding of 2^e * S(fr) * 2^14 with
+//    i = 16384 e + fr and S(fr) the Simpson mean of 2^x over cell fr of [0, 1): glibc's pow(2, x)
+//    scales exactly with the integer part of x.  Only bits 51..20 of S(fr) * 2^52 can reach a
+//    result (e <= 17): xexp[16384] of 32 bits, 64 KiB, leading one implied.
+//  * flog[i] = round(16384 log2(i)) - 14 * 16384 for all but 60 entries, all below 2048: the
+//    first 2048 entries are kept, the rest is evaluated from a 512-segment quadratic of
+//    16384 log2(1 + u) (error < 1e-5; results closer than 1e-4 to a rounding boundary are
+//    NOT trusted: the kernel then reads the full table) -- lseg[512] = {integer part, fraction,
+//    slope, curvature}.
+// ldpc_wht_compact_selfcheck() replays the kernels' arithmetic over every index of both tables.
+void ldpc_build_wht_compact(WhtCompact &c) {
+  c.xexp.assign(kWhtFrac, 0);
+  for (int fr = 0; fr < kWhtFrac; fr++) {
+    const double d = fr * kPrec;
+    const double mid = std::pow(2, d), right = std::pow(2, d - 0.5 * kPrec), left = std::pow(2, d + 0.5 * kPrec);
+    const double S = (4 * mid + right + left) / 6.0;              // in [1, 2)
+    const uint64_t X = (uint64_t)std::ldexp(S, 52);               // exact: S has 52 fraction bits
+    c.xexp[fr] = (uint32_t)(X >> 20);                             // bits 51..20; bit 52 is the implied one
+  }
+  c.lseg.assign((size_t)kWhtSeg * 4, 0.0f);
+  c.lsegi.assign(kWhtSeg, 0);
+  const double ln2 = std::log(2.0);
+  for (int h = 0; h < kWhtSeg; h++) {
+    const double mh = 1.0 + (h + 0.5) / kWhtSeg;
+    const double c0 = 16384.0 * std::log(mh) / ln2;
+    const double ci = std::floor(c0);
+    c.lsegi[h] = (int32_t)ci;
+    c.lseg[(size_t)h * 4 + 0] = (float)(c0 - ci);
+    c.lseg[(size_t)h * 4 + 1] = (float)(16384.0 / (ln2 * mh));
+    c.lseg[(size_t)h * 4 + 2] = (float)(-16384.0 / (2.0 * ln2 * mh * mh));
+  }
+}
+
+// The kernels' fexp (gf_engine.hip w_fexp_c), restated
+uint32_t ldpc_wht_fexp_compact(const WhtCompact &c, int x) {
+  const int L = 1 << (6 + kDeci);
+  x = x < -L ? -L : x;
+  x = x > L - 1 ? L - 1 : x;
+  if (x > 17 * kWhtFrac) return 1u << 31;
+  const int e = x >> kDeci, fr = x & (kWhtFrac - 1);
+  const int sh = 18 - e;                                          // >= 1
+  if (sh >= 34) return 0;
+  const uint64_t Y = (1ull << 32) | c.xexp[fr];
+  return (uint32_t)((Y + (1ull << (sh - 1))) >> sh);
+}
+
+// The kernels' flog fast path for 2048 <= i < 2^20; *defer = the result is not trusted
+int ldpc_wht_flog_compact(const WhtCompact &c, int i, bool *defer) {
+  int e = 31;
+  while (!((unsigned)i >> e)) e--;
+  const int r = i - (1 << e), sh = e - 9;
+  const int h = r >> sh, lo = r & ((1 << sh) - 1);
+  const float t = std::ldexp((float)lo, -e) - 0x1p-10f;
+  const float *q = &c.lseg[(size_t)h * 4];
+  const float w = std::fmaf(t, std::fmaf(t, q[2], q[1]), q[0]);
+  const float fl = std::floor(w + 0.5f);
+  *defer = std::fabs((w - fl)) > 0.5f - 1e-4f;
+  return c.lsegi[h] + kFmul * (e - 14) + (int)fl;
+}
+
+long ldpc_wht_compact_selfcheck(long stats[4]) {
+  std::vector<int32_t> flog;
+  std::vector<uint32_t> fexp;
+  ldpc_build_wht_tables(flog, fexp);
+  WhtCompact c;
+  ldpc_build_wht_compact(c);
+  const int L = 1 << (6 + kDeci);
+  long bad_exp = 0, bad_log = 0, deferred = 0;
+  for (int i = -L; i < L; i++)
+    if (ldpc_wht_fexp_compact(c, i) != fexp[(size_t)(i + L)]) bad_exp++;
+  for (int i = kWhtSmall; i < L; i++) {
+    bool d;
+    const int v = ldpc_wht_flog_compact(c, i, &d);
+    if (d) deferred++;
+    else if (v != flog[i]) bad_log++;
+  }
+  stats[0] = bad_exp; stats[1] = bad_log; stats[2] = deferred; stats[3] = kWhtSmall;
+  return bad_exp + bad_log;
+}
+
 // --- GF(q) ---
 // GF(2^p): discrete-log tables of the primitive polynomials whose powers are
 // the reference's expq literals (GFq_LDPC_NTT.c:25-92); prime q: mod q

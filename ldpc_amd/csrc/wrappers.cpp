@@ -245,6 +245,13 @@ int single_frame(const char *file, int alg, int iteration, const int *x, const i
 
 }  // namespace
 
+extern "C" int64_t ldpc_wht_tables_selfcheck(int64_t *stats) {
+  long st[4] = {0, 0, 0, 0};
+  const long bad = ldpc_wht_compact_selfcheck(st);
+  if (stats) for (int i = 0; i < 4; i++) stats[i] = st[i];
+  return bad;
+}
+
 extern "C" void ldpc_set_seed(uint64_t seed) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_state = seed ? seed : clock_seed();

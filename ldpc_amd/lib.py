@@ -100,6 +100,8 @@ def load_library():
     L.ldpc_mc_generate.argtypes = [vp, C.POINTER(_McOpts), ip, vp, vp, vp]
     L.ldpc_mc_last_pass.argtypes = [vp, ip, vp, vp, vp, vp]
     L.ldpc_mc_set_qlc_channel.argtypes = [vp, vp, ip]
+    L.ldpc_wht_tables_selfcheck.argtypes = [vp]
+    L.ldpc_wht_tables_selfcheck.restype = C.c_int64
     L.ldpc_set_seed.argtypes = [C.c_uint64]
     L.ldpc_set_seed.restype = None
     dp, intp = C.POINTER(C.c_double), C.POINTER(C.c_int)

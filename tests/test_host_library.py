@@ -313,3 +313,14 @@ def test_malformed_csr_is_refused(hip):
         assert e.value.code == -1, kw
     with pytest.raises(hip.LdpcError):                          # GF coefficient out of range
         hip.Code.from_csr(4, 2, [0, 2, 4], [0, 1, 2, 3], hval=[1, 2, 3, 4], q=4)
+
+
+def test_compact_wht_tables_are_exact(hip):
+    """The GF(2^p) kernels evaluate Fexp / Flog (GFq_LDPC_NTT.c:196-247) from compact tables in LDS.
+    Their arithmetic, restated on the host, must reproduce all 2^21 entries of fexp and all 2^20
+    entries of flog of initlogexptab2() -- exactly, or by handing the argument back to the full
+    table (a few hundred Flog arguments within 1e-4 of a rounding boundary)."""
+    st = np.zeros(4, np.int64)
+    bad = hip.load_library().ldpc_wht_tables_selfcheck(st.ctypes.data)
+    assert bad == 0 and st[0] == 0 and st[1] == 0
+    assert 0 < st[2] < 1000 and st[3] == 2048
