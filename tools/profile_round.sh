@@ -1,15 +1,17 @@
+# Round profile of the headline benchmark, run on the GPU box from the repo root:
+#   bash tools/profile_round.sh r02
+# -> gpurun_out/<tag>/: the bench line (with live counters, also written to profiles/<tag>_counters.json by
+#    --save-counters), rocprofv3 --kernel-trace --stats of the same command, and the float legs.
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01b
+O=gpurun_out/$TAG
 mkdir -p $O
-timeout -k 10 200 python3 bench.py > $O/bench_q88.json 2> $O/bench_q88.err
-timeout -k 10 200 python3 bench.py --alg f32 > $O/bench_f32.json 2> $O/bench_f32.err
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $O/kt_q88 -o p --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-secondary > $O/kt_q88.log 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $O/kt_f32 -o p --output-format csv -- python3 bench.py --alg f32 --steps 4 --warmup 1 --no-cpu --no-secondary > $O/kt_f32.log 2>&1
-for alg in q88 f32; do
-timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE -d $O/pf_$alg -o p --output-format csv -- python3 bench.py --alg $alg --steps 2 --warmup 0 --no-cpu --no-profile --no-secondary > $O/pf_$alg.log 2>&1
-timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE -d $O/pw_$alg -o p --output-format csv -- python3 bench.py --alg $alg --steps 2 --warmup 0 --no-cpu --no-profile --no-secondary > $O/pw_$alg.log 2>&1
-python3 tools/pmc_sum.py $O/pf_$alg/p_counter_collection.csv fused > $O/pmc_hbm_$alg.txt
-python3 tools/pmc_sum.py $O/pw_$alg/p_counter_collection.csv fused >> $O/pmc_hbm_$alg.txt
-done
-cat $O/bench_q88.json | cut -c1-200; cat $O/bench_f32.json | cut -c1-200; cat $O/pmc_hbm_*.txt
+timeout -k 10 400 python3 bench.py --save-counters $O/counters.json > $O/bench_q88.json 2> $O/bench_q88.err
+timeout -k 10 300 python3 bench.py --alg f32 --no-cpu --save-counters $O/counters.json > $O/bench_f32.json 2> $O/bench_f32.err
+timeout -k 10 300 python3 bench.py --alg f64 --frames 16384 --no-cpu --no-pmc > $O/bench_f64.json 2> $O/bench_f64.err
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $O/kt_q88 -o p --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-secondary --no-pmc > $O/kt_q88.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $O/kt_f32 -o p --output-format csv -- python3 bench.py --alg f32 --steps 4 --warmup 1 --no-cpu --no-secondary --no-pmc > $O/kt_f32.log 2>&1
+cp $(find $O/kt_q88 -name "*kernel_stats.csv") $O/fused_kernel_stats.csv
+cp $(find $O/kt_f32 -name "*kernel_stats.csv") $O/fused_f32_kernel_stats.csv
+cut -c1-300 $O/bench_q88.json; head -3 $O/fused_kernel_stats.csv | cut -c1-200
