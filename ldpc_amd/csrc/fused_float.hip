@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -153,17 +154,34 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
           uint32_t arg = 0, p = 0, sg[NW];
 #pragma unroll
           for (int w = 0; w < NW; w++) sg[w] = 0;
-          for (int k = 0; k < a.RM; k++) {
-            const T S = sumL[col[(size_t)k * B]];
-            p ^= (uint32_t)(S < (T)0);
-            T co = ((uint32_t)k == oarg[r]) ? om2[r] : om1[r];
-            if ((osg[r][NW == 1 ? 0 : (k >> 5)] >> (k & 31)) & 1u) co = -co;
-            const T q = S - co;                                   // :150
-            const T mag = q < (T)0 ? -q : q;
-            if (q < (T)0) sg[NW == 1 ? 0 : (k >> 5)] |= 1u << (k & 31);
-            if (mag < m1) { m2 = m1; m1 = mag; arg = (uint32_t)k; }
-            else if (mag < m2) { m2 = mag; }
-          }
+          // eight slots at a time (then the rest in pairs: RM is even): their indices (global, L2)
+          // and then their sums (LDS) are all requested before the first is used -- one index
+          // load per slot in a dependent chain was most of this kernel's time.
+          auto slots = [&](int k0, auto ck_c) {
+            constexpr int CK = decltype(ck_c)::value;
+            int wv[CK];
+            T Sv[CK];
+#pragma unroll
+            for (int jj = 0; jj < CK; jj++) wv[jj] = (int)col[(size_t)(k0 + jj) * B];
+#pragma unroll
+            for (int jj = 0; jj < CK; jj++) Sv[jj] = sumL[wv[jj]];
+#pragma unroll
+            for (int jj = 0; jj < CK; jj++) {
+              const int k = k0 + jj;
+              const T S = Sv[jj];
+              p ^= (uint32_t)(S < (T)0);
+              T co = ((uint32_t)k == oarg[r]) ? om2[r] : om1[r];
+              if ((osg[r][NW == 1 ? 0 : (k >> 5)] >> (k & 31)) & 1u) co = -co;
+              const T q = S - co;                                   // :150
+              const T mag = q < (T)0 ? -q : q;
+              if (q < (T)0) sg[NW == 1 ? 0 : (k >> 5)] |= 1u << (k & 31);
+              if (mag < m1) { m2 = m1; m1 = mag; arg = (uint32_t)k; }
+              else if (mag < m2) { m2 = mag; }
+            }
+          };
+          int k0 = 0;
+          for (; k0 + 8 <= a.RM; k0 += 8) slots(k0, std::integral_constant<int, 8>{});
+          for (; k0 < a.RM; k0 += 2) slots(k0, std::integral_constant<int, 2>{});
           par[r] = (int)p;
           bad |= (int)p ^ sbit[r];
           // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:177-178)
@@ -186,17 +204,45 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
       if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
       // ---- variable pass: sum = q0 + c2v in column-slot order (:146-148)
-      for (int w = tid; w < a.var_words; w += B) {
-        T sum = q0L[w];
-        for (int kk = 0; kk < a.cmax; kk++) {
-          const uint32_t e = a.vtab[(size_t)kk * a.var_words + w];
-          const int j = (int)(e >> 8), p = (int)(e & 0xffu);
-          const uint32_t sw = sgL[SGW * j + (NW == 1 ? 0 : (p >> 5))];
-          const uint32_t arg = QG ? (uint32_t)argL[j] : sgL[SGW * j + NW];
-          const T mg = magL[2 * j + (arg == (uint32_t)p ? 1 : 0)];
-          sum = sum + (((sw >> (p & 31)) & 1u) ? -mg : mg);
-        }
-        sumL[w] = sum + (T)0;
+      // up to four variables and four of their edges at a time, every edge-table entry (global,
+      // L2) requested before the first record is read; each variable's messages are still added
+      // in slot order.
+      auto variables = [&](int w0, auto vu_c) {
+        constexpr int VU = decltype(vu_c)::value;
+        T sum[VU];
+#pragma unroll
+        for (int u = 0; u < VU; u++) sum[u] = q0L[w0 + u * B];
+        auto edges = [&](int kk0, auto kc_c) {
+          constexpr int KC = decltype(kc_c)::value;
+          uint32_t ev[VU][KC];
+#pragma unroll
+          for (int u = 0; u < VU; u++)
+#pragma unroll
+            for (int c = 0; c < KC; c++) ev[u][c] = a.vtab[(size_t)(kk0 + c) * a.var_words + w0 + u * B];
+#pragma unroll
+          for (int c = 0; c < KC; c++)
+#pragma unroll
+            for (int u = 0; u < VU; u++) {
+              const uint32_t e = ev[u][c];
+              const int j = (int)(e >> 8), p = (int)(e & 0xffu);
+              const uint32_t sw = sgL[SGW * j + (NW == 1 ? 0 : (p >> 5))];
+              const uint32_t arg = QG ? (uint32_t)argL[j] : sgL[SGW * j + NW];
+              const T mg = magL[2 * j + (arg == (uint32_t)p ? 1 : 0)];
+              sum[u] = sum[u] + (((sw >> (p & 31)) & 1u) ? -mg : mg);
+            }
+        };
+        int kk0 = 0;
+        for (; kk0 + 4 <= a.cmax; kk0 += 4) edges(kk0, std::integral_constant<int, 4>{});
+        if (a.cmax - kk0 == 3) edges(kk0, std::integral_constant<int, 3>{});
+        else if (a.cmax - kk0 == 2) edges(kk0, std::integral_constant<int, 2>{});
+        else if (a.cmax - kk0 == 1) edges(kk0, std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int u = 0; u < VU; u++) sumL[w0 + u * B] = sum[u] + (T)0;
+      };
+      {
+        int w0 = tid;
+        for (; w0 + 3 * B < a.var_words; w0 += 4 * B) variables(w0, std::integral_constant<int, 4>{});
+        for (; w0 < a.var_words; w0 += B) variables(w0, std::integral_constant<int, 1>{});
       }
       __syncthreads();
     }
