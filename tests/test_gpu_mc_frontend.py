@@ -130,6 +130,29 @@ def test_headline_code_runs_on_device(hip, oracle):
     assert got["bit_errors"] == sum(int((r["bits"].astype(np.uint8) != x[f]).sum()) for f, r in enumerate(res))
 
 
+def test_million_frames_at_the_benchmark_size(hip):
+    """configs[1] at its full size -- 10^6 frames of PEG-16000, Q8.8 min-sum, passes of 65 536 --
+    through size-independent properties (no CPU decoder finishes this in test time): random
+    source words with s = H x (the reference's syndrome-decoding round trip, enc() -> bsc() ->
+    dec() -> HamDist): a frame that reaches its syndrome at p far below threshold must have
+    reached x itself (no undetected error, no bit error on converged frames); far above threshold
+    no frame converges and every frame runs exactly loop_max iterations (the benchmark's
+    operating point); and the counters of the whole run equal the sum over two shards of it."""
+    name, F = "peg_16000_3_0.9.txt", 1_000_000
+    code, dec, mc = _setup(hip, name, hip.ALG.MINSUM_Q88, max_frames=65536)
+    lo = mc.run(F, ref.BSC_EXACT, 0.0005, ref.I16, 30, seed=5)
+    assert lo["frames"] == F and lo["undetected"] == 0 and lo["bit_errors_converged"] == 0
+    assert lo["not_converged"] < F // 1000 and (lo["bit_errors"] > 0) == (lo["not_converged"] > 0)
+    assert F <= lo["iterations"] < 4 * F                       # early exit: one to three iterations per frame
+    a = mc.run(400_000, ref.BSC_EXACT, 0.0005, ref.I16, 30, seed=5, first_frame=0)
+    b = mc.run(F - 400_000, ref.BSC_EXACT, 0.0005, ref.I16, 30, seed=5, first_frame=400_000)
+    assert lo == {k: a[k] + b[k] for k in lo}
+    _, dec2, mc2 = _setup(hip, name, hip.ALG.MINSUM_Q88, max_frames=65536, early_exit=False)
+    hi = mc2.run(F, ref.BSC_IID, 0.02, ref.I16, 10, seed=6)
+    assert hi["frames"] == F and hi["not_converged"] == F and hi["iterations"] == 10 * F
+    assert hi["frames_in_error"] == F and hi["undetected"] == 0
+
+
 def test_bad_arguments(hip):
     code, dec, mc = _setup(hip, "204.33.484.txt", hip.ALG.MINSUM_Q88)
     with pytest.raises(hip.LdpcError):
