@@ -19,7 +19,7 @@
 //                  (:163-166) and min1/min2 of |v2c| (cap 200, :169) -> new compressed
 //                  state to LDS.  sign(S) over the slots is the syndrome of the hard
 //                  decisions after the previous iteration (enc() + HamDist, :200-203).
-//   barrier        (__syncthreads_or: the exit test)
+//   barrier        (workgroup-wide OR of "some check unsatisfied": the exit test)
 //   variable pass  each variable thread rebuilds sum = q0 + c2v_0 + c2v_1 + ... in slot
 //                  order from the compressed check states (:146-148, :190-193).
 //   barrier
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
       sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
       par[r] = 0;
     }
+    if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
     __syncthreads();
 
     int it_done = a.max_iter, ok = 0;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
           om1[r] = m1; om2[r] = m2; oarg[r] = arg;
         }
       }
-      const int any_bad = __syncthreads_or(bad);
+      const int any_bad = fq_block_or(bad, frame_slot + 1, t);   // (one barrier; __syncthreads_or is three)
       // the reference tests H*bits == s after each iteration (:200-203), not before the first
       if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
       sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
       par[r] = 0;
     }
+    if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
     __syncthreads();
 
     int it_done = a.max_iter, ok = 0;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
         else parity_only(std::integral_constant<int, CPT - 1>{});
       } else if (wave_full) check_pass(std::integral_constant<int, CPT>{});
       else check_pass(std::integral_constant<int, CPT - 1>{});
-      const int any_bad = __syncthreads_or(bad);
+      const int any_bad = fq_block_or(bad, frame_slot + 1, t);   // (one barrier; __syncthreads_or is three)
       if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
       // ---- variable pass

@@ -328,6 +328,20 @@ __device__ __forceinline__ lds_int *fq_slot_ptr(unsigned base, unsigned packed) 
   return (lds_int *)(unsigned long)r;
 }
 
+// Workgroup-wide OR with ONE barrier (__syncthreads_or compiles to three): every wavefront that
+// saw a set bit raises the flag of this iteration's parity, the barrier that separates the two
+// phases publishes it, and lane 0 lowers the other parity's flag for the iteration after next
+// (every wavefront has read that one before it arrived here; it is raised again only behind the
+// next barrier).  flags[2] must be zero when a frame starts.
+__device__ __forceinline__ int fq_block_or(int bad, int *flags, int t) {
+  int *f = flags + (t & 1);
+  if (__ballot(bad != 0) != 0 && (threadIdx.x & 63) == 0) *f = 1;
+  __syncthreads();
+  const int r = *f;
+  if (threadIdx.x == 0) flags[(t & 1) ^ 1] = 0;
+  return r;
+}
+
 // SH: LDS byte offset = index << SH (0 when the offsets themselves fit 16 bits)
 template <int CPT, int R2, int SH, int LB, int MINW>
 __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
@@ -427,6 +441,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
       par[r] = 0;
     }
+    if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
     __syncthreads();
 
     int it_done = a.max_iter, ok = 0;
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         else parity_only(std::integral_constant<int, CPT - 1>{});
       } else if (wave_full) phase_a(std::integral_constant<int, CPT>{});
       else phase_a(std::integral_constant<int, CPT - 1>{});
-      const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : __syncthreads_or(bad);
+      const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : fq_block_or(bad, frame_slot + 1, t);
       if (!any_bad) { it_done = t - 1; ok = 1; break; }
       if (t == a.max_iter + 1) break;
       for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
