@@ -44,6 +44,15 @@
 #define I_ASHR(d, x, y, z) "v_ashrrev_i32 " #d ", 31, " #y
 #define I_MIN3U(d, x, y, z) "v_min3_u32 " #d ", " #x ", " #y ", " #z
 #define I_MAX3F(d, x, y, z) "v_max3_f32 " #d ", " #x ", " #y ", " #z
+#define I_LSHR16(d, x, y, z) "v_lshrrev_b32 " #d ", 16, " #y
+#define I_ASHR16(d, x, y, z) "v_ashrrev_i32 " #d ", 16, " #y
+#define I_LSHL16(d, x, y, z) "v_lshlrev_b32 " #d ", 16, " #y
+#define I_LSHRV(d, x, y, z) "v_lshrrev_b32 " #d ", " #x ", " #y
+#define I_CVTUB(d, x, y, z) "v_cvt_f32_ubyte0 " #d ", " #y
+#define I_CVTF16(d, x, y, z) "v_cvt_f32_f16 " #d ", " #y
+#define I_SUBREV(d, x, y, z) "v_subrev_f32 " #d ", " #x ", " #y
+#define I_ADDF(d, x, y, z) "v_add_f32 " #d ", " #x ", " #y
+#define I_XNOR(d, x, y, z) "v_xnor_b32 " #d ", " #x ", " #y
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(unsigned *out, int iters, unsigned s0) {
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(1024) void k(unsigned *out, int iters, unsigned s0)
     CASE(14, I_ADD3) CASE(15, I_LSHLADD) CASE(16, I_XAD) CASE(17, I_MOV) CASE(18, I_PERM) CASE(19, I_BFE) CASE(20, I_SUBABS)
     CASE(21, I_SUBNEG) CASE(22, I_CNDS) CASE(23, I_CMP) CASE(24, I_CMPS) CASE(25, I_ADDCO) CASE(26, I_PKADDU16)
     CASE(27, I_PKSUBI16) CASE(28, I_PKMAXI16) CASE(29, I_SADU8) CASE(30, I_ADDF16) CASE(31, I_PKADDF16) CASE(32, I_PKMINF16)
-    CASE(33, I_DPPXOR) CASE(34, I_SDWAXOR) CASE(35, I_ANDSDWA) CASE(36, I_SUBF_SDWA) CASE(37, I_ASHR) CASE(38, I_MIN3U) CASE(39, I_MAX3F)
+    CASE(33, I_DPPXOR) CASE(34, I_SDWAXOR) CASE(35, I_ANDSDWA) CASE(36, I_SUBF_SDWA) CASE(37, I_ASHR) CASE(38, I_MIN3U) CASE(39, I_MAX3F) CASE(40, I_LSHR16) CASE(41, I_ASHR16) CASE(42, I_LSHL16) CASE(43, I_LSHRV) CASE(44, I_CVTUB) CASE(45, I_CVTF16) CASE(46, I_SUBREV) CASE(47, I_ADDF) CASE(48, I_XNOR)
   }
   out[blockIdx.x * 1024 + threadIdx.x] = a ^ b ^ c ^ d;
 }
@@ -81,6 +90,6 @@ int main() {
   R(14, "v_add3_u32") R(15, "v_lshl_add_u32") R(16, "v_xad_u32") R(17, "v_mov_b32") R(18, "v_perm_b32") R(19, "v_bfe_u32") R(20, "v_sub_f32 |x|")
   R(21, "v_sub_f32 -x") R(22, "v_cndmask vcc") R(23, "v_cmp -> vcc") R(24, "v_cmp -> sgpr") R(25, "v_add_co_u32") R(26, "v_pk_add_u16")
   R(27, "v_pk_sub_i16") R(28, "v_pk_max_i16") R(29, "v_sad_u8") R(30, "v_add_f16") R(31, "v_pk_add_f16") R(32, "v_pk_min_f16")
-  R(33, "v_xor_b32 dpp") R(34, "v_xor_b32 sdwa") R(35, "v_and_b32 sdwa") R(36, "v_sub_f32 sdwa") R(37, "v_ashrrev_i32") R(38, "v_min3_u32") R(39, "v_max3_f32")
+  R(33, "v_xor_b32 dpp") R(34, "v_xor_b32 sdwa") R(35, "v_and_b32 sdwa") R(36, "v_sub_f32 sdwa") R(37, "v_ashrrev_i32") R(38, "v_min3_u32") R(39, "v_max3_f32") R(40, "v_lshrrev_b32 16") R(41, "v_ashrrev_i32 16") R(42, "v_lshlrev_b32 16") R(43, "v_lshrrev_b32 var") R(44, "v_cvt_f32_ubyte0") R(45, "v_cvt_f32_f16") R(46, "v_subrev_f32") R(47, "v_add_f32") R(48, "v_xnor_b32")
   return 0;
 }
