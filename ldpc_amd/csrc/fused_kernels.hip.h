@@ -98,7 +98,9 @@ inline FusedKern fused_reg_lookup(int cpt, int r2, int sh) {
 
 // timing experiments only (results wrong when non-zero; tools/probes/build_ablate.sh): 1 no LDS
 // adds in phase B (the arithmetic stays), 2 no LDS reads in phase A (the arithmetic stays, on
-// register values), 4 no barriers inside the iteration loop (and no exit test)
+// register values), 4 no barriers inside the iteration loop (and no exit test); 8 / 16 / 32 / 64 /
+// 128 / 256 / 512: one instruction of the slot loops replaced by a fast-rate one or dropped
+// (alignbit, med3, min, the min1/min2 select, phase B's convert, the key packing, the mask shift)
 #ifndef LDPC_FUSED_ABLATE
 #define LDPC_FUSED_ABLATE 0
 #endif
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(1024) void fused_q88_kernel(FusedArgs a) {
 //
 // Arithmetic: every Q8.8 value is an integer of magnitude < 2^19, which binary32
 // holds exactly, and so is every sum or difference the decoder forms; the sums
-// stay int32 in LDS (ds_add_u32; LDS float atomics are several times slower)
-// and are converted on the way in and out of a check's arithmetic, which runs
-// on floats holding integers.  That buys the VALU shortcuts the inner loop is
+// stay integers in LDS (ds_add_u32; LDS float atomics are several times slower),
+// biased so that their bit pattern reads as a float (FQ_BIAS below), and a check's
+// arithmetic runs on floats holding integers.  That buys the VALU shortcuts the inner loop is
 // built from: |x| and -x are operand modifiers, a sign is moved with one
 // v_bfi, the slot's sign bit is shifted into the mask with one v_alignbit, and
 // min1 / min2 / argmin come from one v_min_u32 + one v_med3_u32 on the key
@@ -275,9 +277,22 @@ __global__ __launch_bounds__(1024) void fused_q88_kernel(FusedArgs a) {
 // positive value, which makes them neutral: sign 0, never a minimum.  What phase
 // B adds to the dummies is bounded per iteration; they are re-armed every
 // iteration.
+//
+// The LDS words carry a bias: word = sum + FQ_BIAS, where FQ_BIAS is the bit pattern of the
+// float 2^23 + 2^21.  Read as a float the word IS 2^23 + 2^21 + sum (integers in [2^23, 2^24)
+// are consecutive bit patterns), so "int -> float" in phase A is one subtraction at the fast
+// VALU rate instead of a v_cvt_f32_i32 at the slow one; phase B's integer adds do not see the
+// bias at all.  Exact while -2^21 <= sum < 2^23 - 2^21: |sum| <= 128.0 + cmax * 200.0 in Q8.8
+// units, which the host checks (fq_cmax_ok).  Dummy words sit 2^24 above the bias -- beyond the
+// exact range, where a float moves 4 per unit of its bit pattern, which is immaterial for a
+// value that only has to stay "huge and positive".
 #define FQ_NDUMMY 256
-#define FQ_BIG (1 << 24)
+#define FQ_BIAS 0x4B200000
+#define FQ_BIASF 10485760.0f /* 2^23 + 2^21 */
+#define FQ_BIG (FQ_BIAS + (1 << 24))
 #define FQ_PADLIMF 4194304.0f /* 2^22 */
+// largest variable degree for which every sum (and every sum - message) stays inside the exact range
+constexpr bool fq_cmax_ok(int cmax) { return 32768 + (cmax + 1) * FQ_CAP < (1 << 21); }
 
 __device__ __forceinline__ unsigned fq_med3u(unsigned a, unsigned b, unsigned c) {
   unsigned r;
@@ -403,26 +418,26 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         for (int i = tid; i < (a.n >> 3); i += B) {
           const fq_u4 v = __builtin_nontemporal_load(p8 + i);
           const fq_u4 w = pos8[i];
-          fsum[w.x & 0xffffu] = (int)(short)(v.x & 0xffffu); fsum[w.x >> 16] = (int)v.x >> 16;
-          fsum[w.y & 0xffffu] = (int)(short)(v.y & 0xffffu); fsum[w.y >> 16] = (int)v.y >> 16;
-          fsum[w.z & 0xffffu] = (int)(short)(v.z & 0xffffu); fsum[w.z >> 16] = (int)v.z >> 16;
-          fsum[w.w & 0xffffu] = (int)(short)(v.w & 0xffffu); fsum[w.w >> 16] = (int)v.w >> 16;
+          fsum[w.x & 0xffffu] = FQ_BIAS + (int)(short)(v.x & 0xffffu); fsum[w.x >> 16] = FQ_BIAS + ((int)v.x >> 16);
+          fsum[w.y & 0xffffu] = FQ_BIAS + (int)(short)(v.y & 0xffffu); fsum[w.y >> 16] = FQ_BIAS + ((int)v.y >> 16);
+          fsum[w.z & 0xffffu] = FQ_BIAS + (int)(short)(v.z & 0xffffu); fsum[w.z >> 16] = FQ_BIAS + ((int)v.z >> 16);
+          fsum[w.w & 0xffffu] = FQ_BIAS + (int)(short)(v.w & 0xffffu); fsum[w.w >> 16] = FQ_BIAS + ((int)v.w >> 16);
         }
       } else if (a.dt == 2) {
         const short *p = (const short *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = p[i];
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = FQ_BIAS + p[i];
       } else if (a.dt == 3) {
         const int *p = (const int *)a.llr + base;
         for (int i = tid; i < a.n; i += B) {
           int v = p[i];
-          fsum[a.pos[i]] = v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
+          fsum[a.pos[i]] = FQ_BIAS + (v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v));
         }
       } else if (a.dt == 1) {
         const float *p = (const float *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = fq_from_real((double)p[i]);
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = FQ_BIAS + fq_from_real((double)p[i]);
       } else {
         const double *p = (const double *)a.llr + base;
-        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = fq_from_real(p[i]);
+        for (int i = tid; i < a.n; i += B) fsum[a.pos[i]] = FQ_BIAS + fq_from_real(p[i]);
       }
       for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // dummies
     }
@@ -455,6 +470,15 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
         // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
         unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW], orot[CPT][NW];
+        // Which lanes have their previous minimum in slot k?  The slot numbers, transposed into one
+        // lane mask per bit (KB compares per check and iteration); the mask of slot k is then an
+        // AND of those on the scalar unit, which has nothing else to do, instead of a vector
+        // compare per slot.
+        unsigned long long ab[CPT][KB];
+#pragma unroll
+        for (int r = 0; r < NA; r++)
+#pragma unroll
+          for (int b = 0; b < KB; b++) ab[r][b] = __ballot((oarg[r] >> b) & 1u);
 #pragma unroll
         for (int r = 0; r < NA; r++) {
           k1[r] = k2m[r] = 0xffffffffu;
@@ -486,14 +510,32 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             for (int r = 0; r < NA; r++) {
               const int k = kc + j;
               if (k >= RM) continue;
-              // hard-decision parity, two slots per v_bitop3 (x ^ y ^ z); CH and RM are even
-              if ((j & 1) == 0) pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
-              const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-              const float q = (float)S[r][j] - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
-              orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
+              // the sums as floats (the words are biased: see FQ_BIAS), two slots at a time
+              if ((j & 1) == 0) {
+                S[r][j] = (int)__float_as_uint(__uint_as_float((unsigned)S[r][j]) - FQ_BIASF);
+                S[r][j + 1] = (int)__float_as_uint(__uint_as_float((unsigned)S[r][j + 1]) - FQ_BIASF);
+                // hard-decision parity, two slots per v_bitop3 (x ^ y ^ z); CH and RM are even
+                pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
+              }
+              float mo;
+              if (LDPC_FUSED_ABLATE & 64) mo = om1[r];
+              else {
+                unsigned long long in_k = (k & 1) ? ab[r][0] : ~ab[r][0];
+#pragma unroll
+                for (int b = 1; b < KB; b++) in_k &= ((k >> b) & 1) ? ab[r][b] : ~ab[r][b];
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
+              }
+              const float q = __uint_as_float((unsigned)S[r][j]) - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
+              if (!(LDPC_FUSED_ABLATE & 512)) orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
+              if (LDPC_FUSED_ABLATE & 8) sg[r][k / 32] |= __float_as_uint(q);
+              else
               sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
-              const unsigned key = FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
+              const unsigned key = (LDPC_FUSED_ABLATE & 256) ? __float_as_uint(q) : FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
+              if (LDPC_FUSED_ABLATE & 16) k2m[r] ^= key & k1[r];
+              else
               k2m[r] = fq_med3u(k1[r], key, k2m[r]);
+              if (LDPC_FUSED_ABLATE & 32) k1[r] &= key;
+              else
               k1[r] = min(k1[r], key);
             }
         }
@@ -544,8 +586,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           unsigned pp = 0;
 #pragma unroll
           for (int k = 0; k < RM; k += 2) {
-            const int s0 = *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
-            const int s1 = *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]);
+            const int s0 = *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]) - FQ_BIAS;
+            const int s1 = *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) - FQ_BIAS;
             pp = __builtin_amdgcn_bitop3_b32(pp, (unsigned)s0, (unsigned)s1, 0x96);
           }
           par[r] = (int)(pp >> 31);
@@ -584,7 +626,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
             nrot[k / 32] = fq_shl1(nrot[k / 32]);
             prot[k / 32] = fq_shl1(prot[k / 32]);
-            const int delta = (int)(cn - co);
+            const int delta = (LDPC_FUSED_ABLATE & 128) ? (int)__float_as_uint(cn - co) : (int)(cn - co);
             if (LDPC_FUSED_ABLATE & 1) asm volatile("" ::"v"(delta), "v"(dst));
             else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -614,20 +656,19 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       for (int i = tid; i < (a.n >> 3); i += B) {
         const fq_u4 w = pos8[i];
         fq_u2 b;
-        b.x = ((unsigned)fsum[w.x & 0xffffu] >> 31) | (((unsigned)fsum[w.x >> 16] >> 31) << 8) |
-              (((unsigned)fsum[w.y & 0xffffu] >> 31) << 16) | (((unsigned)fsum[w.y >> 16] >> 31) << 24);
-        b.y = ((unsigned)fsum[w.z & 0xffffu] >> 31) | (((unsigned)fsum[w.z >> 16] >> 31) << 8) |
-              (((unsigned)fsum[w.w & 0xffffu] >> 31) << 16) | (((unsigned)fsum[w.w >> 16] >> 31) << 24);
+        auto neg = [&](unsigned word) { return (unsigned)(fsum[word] - FQ_BIAS) >> 31; };
+        b.x = neg(w.x & 0xffffu) | (neg(w.x >> 16) << 8) | (neg(w.y & 0xffffu) << 16) | (neg(w.y >> 16) << 24);
+        b.y = neg(w.z & 0xffffu) | (neg(w.z >> 16) << 8) | (neg(w.w & 0xffffu) << 16) | (neg(w.w >> 16) << 24);
         __builtin_nontemporal_store(b, o8 + i);
       }
     } else if (a.bits) {
       uint8_t *o = a.bits + (size_t)frame * a.n;
-      for (int i = tid; i < a.n; i += B) o[i] = fsum[a.pos[i]] < 0;
+      for (int i = tid; i < a.n; i += B) o[i] = fsum[a.pos[i]] < FQ_BIAS;
     }
     if (a.llr_out) {
       float *o = a.llr_out + (size_t)frame * a.n;
       for (int i = tid; i < a.n; i += B) {
-        int s = fsum[a.pos[i]];
+        int s = fsum[a.pos[i]] - FQ_BIAS;
         s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);   // float_to_fix(sum), :303
         o[i] = (float)s * (1.0f / 256.0f);
       }

@@ -663,8 +663,9 @@ struct FusedQ88Engine : Engine {
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
+    // (fq_cmax_ok: the sums of the heaviest variable stay inside the exact range of the biased LDS words)
     return c.q == 2 && c.n <= 65535 && c.rmax <= 64 && (size_t)(c.n + FQ_NDUMMY + 4) * 4 <= 160 * 1024 &&
-           (c.m + 63) / 64 <= 8 * 16;
+           (c.m + 63) / 64 <= 8 * 16 && fq_cmax_ok(c.cmax);
   }
   size_t llr_elems_per_frame() const override { return (size_t)n; }
 
@@ -733,6 +734,7 @@ struct FusedQ88Engine : Engine {
         }
       use_reg = bestW > 0;
     }
+
     if (!use_reg) {
       bestG = env_g >= 1 && env_g <= wg_per_cu ? env_g : std::min(wg_per_cu, 4);
       const int maxW = bestG >= 2 ? 8 : 16;
@@ -806,6 +808,9 @@ struct FusedQ88Engine : Engine {
       if (lds + fa.sharedSizeBytes > 160 * 1024) { ldpc_set_error("fused decoder: frame does not fit in LDS"); return LDPC_ERR_UNSUPPORTED; }
     }
     if ((rc = d_counter.ensure(256))) return rc;
+    if (getenv("LDPC_HIP_VERBOSE"))
+      fprintf(stderr, "ldpc_hip: fused Q8.8 decoder: %d threads x %d workgroup(s) per CU, %d check(s) per thread, %s, %zu B LDS\n",
+              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : "generic kernel", lds);
     return LDPC_OK;
   }
 
