@@ -98,9 +98,9 @@ inline FusedKern fused_reg_lookup(int cpt, int r2, int sh) {
 
 // timing experiments only (results wrong when non-zero; tools/probes/build_ablate.sh): 1 no LDS
 // adds in phase B (the arithmetic stays), 2 no LDS reads in phase A (the arithmetic stays, on
-// register values), 4 no barriers inside the iteration loop (and no exit test); 8 / 16 / 32 / 64 /
-// 128 / 256 / 512: one instruction of the slot loops replaced by a fast-rate one or dropped
-// (alignbit, med3, min, the min1/min2 select, phase B's convert, the key packing, the mask shift)
+// register values), 4 no barriers inside the iteration loop (and no exit test); 16 / 32 / 64 /
+// 128 / 256: one instruction of the slot loops replaced by a fast-rate one or dropped
+// (med3, min, the min1/min2 select, phase B's convert, the key packing)
 #ifndef LDPC_FUSED_ABLATE
 #define LDPC_FUSED_ABLATE 0
 #endif
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         constexpr int NA = decltype(na_c)::value;
         // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
         // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
-        unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW], orot[CPT][NW];
+        unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW];
         // Which lanes have their previous minimum in slot k?  The slot numbers, transposed into one
         // lane mask per bit (KB compares per check and iteration); the mask of slot k is then an
         // AND of those on the scalar unit, which has nothing else to do, instead of a vector
@@ -484,10 +484,10 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           k1[r] = k2m[r] = 0xffffffffu;
           pp[r] = 0;
 #pragma unroll
-          for (int w = 0; w < NW; w++) {
-            sg[r][w] = 0;
-            orot[r][w] = osg[r][w] << (32 - WB);   // old sign of the slot in turn: always bit 31
-          }
+          // One register per mask word serves both directions: the old signs leave at the top
+          // (the slot in turn is always bit 31) while the new ones enter at the bottom, one
+          // v_alignbit per slot; after the word's last slot only new signs are left.
+          for (int w = 0; w < NW; w++) sg[r][w] = osg[r][w] << (32 - WB);
         }
         // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
         // reads in flight and CPT independent min chains
@@ -525,10 +525,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
                 for (int b = 1; b < KB; b++) in_k &= ((k >> b) & 1) ? ab[r][b] : ~ab[r][b];
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
               }
-              const float q = __uint_as_float((unsigned)S[r][j]) - __uint_as_float(FQ_ANDOR(orot[r][k / 32], 0x80000000u, __float_as_uint(mo)));
-              if (!(LDPC_FUSED_ABLATE & 512)) orot[r][k / 32] = fq_shl1(orot[r][k / 32]);
-              if (LDPC_FUSED_ABLATE & 8) sg[r][k / 32] |= __float_as_uint(q);
-              else
+              const float q = __uint_as_float((unsigned)S[r][j]) - __uint_as_float(FQ_ANDOR(sg[r][k / 32], 0x80000000u, __float_as_uint(mo)));
               sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
               const unsigned key = (LDPC_FUSED_ABLATE & 256) ? __float_as_uint(q) : FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
               if (LDPC_FUSED_ABLATE & 16) k2m[r] ^= key & k1[r];
