@@ -657,9 +657,9 @@ struct FusedQ88Engine : Engine {
   int n = 0, m = 0, rmax = 0;
   int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
   size_t lds = 0;
-  DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT;
+  DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT, d_timing;
   LdsSchedule sched;
-  bool use_reg = false;
+  bool use_reg = false, fresh = false;
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
@@ -770,6 +770,18 @@ struct FusedQ88Engine : Engine {
         small = (size_t)(sched.words - 1) * 4 + fa.sharedSizeBytes <= 65535;
       }
       if (!small) kern = fused_reg_lookup(rounds, r2, 2);
+      // two sum arrays + q0 in LDS (phase B without the old messages) where they fit next to
+      // the workgroups that share the CU
+      int want_fresh = 1;
+      if (const char *e = getenv("LDPC_HIP_FUSED_FRESH")) want_fresh = atoi(e);
+      if (small && want_fresh && sched.words <= FQ_FRESH_WORDS &&
+          (size_t)wg_per_cu * fq_fresh_lds_bytes(sched.words) <= 160 * 1024) {
+        if (FusedKern k2 = fused_reg_lookup(rounds, r2, 1)) {
+          hipFuncAttributes fa;
+          HIPCHK(hipFuncGetAttributes(&fa, (const void *)k2));
+          if (fa.sharedSizeBytes == 0) { kern = k2; fresh = true; lds = fq_fresh_lds_bytes(sched.words); }
+        }
+      }
       if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
       if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
       if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
@@ -810,7 +822,7 @@ struct FusedQ88Engine : Engine {
     if ((rc = d_counter.ensure(256))) return rc;
     if (getenv("LDPC_HIP_VERBOSE"))
       fprintf(stderr, "ldpc_hip: fused Q8.8 decoder: %d threads x %d workgroup(s) per CU, %d check(s) per thread, %s, %zu B LDS\n",
-              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : "generic kernel", lds);
+              block, wg_per_cu, rounds, !use_reg ? "generic kernel" : fresh ? "register-cached kernel, two sum arrays" : "register-cached kernel", lds);
     return LDPC_OK;
   }
 
@@ -835,6 +847,13 @@ struct FusedQ88Engine : Engine {
     a.pos = d_pos.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
     a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
+    a.timing = nullptr;
+    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;   // (only timing builds of the kernel write it)
+    if (timing) {
+      if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
+      HIPCHK(hipMemsetAsync(d_timing.p, 0, 16 * 8 * sizeof(unsigned long long), st));
+      a.timing = d_timing.as<unsigned long long>();
+    }
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
     prof_begin(K_FUSED, st);
@@ -842,6 +861,15 @@ struct FusedQ88Engine : Engine {
     LAUNCHCHK("fused_q88_kernel");
     prof_end(st);
     last_iterations = max_iter;
+    if (timing) {
+      unsigned long long h[16 * 8];
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(h, d_timing.p, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "ldpc_hip: fused kernel cycles per wavefront slot, summed over %ld workgroups: phase A | wait | phase B | wait | whole frames | stage-in | its barrier | outputs\n", grid);
+      for (int w = 0; w < block / 64; w++)
+        fprintf(stderr, "  wave %2d: %12llu %12llu %12llu %12llu %12llu %12llu %12llu %12llu\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],
+                h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6], h[w * 8 + 7]);
+    }
     return LDPC_OK;
   }
 

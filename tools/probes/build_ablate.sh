@@ -5,7 +5,9 @@ set -e
 cd "$(dirname "$0")/../../ldpc_amd/csrc"
 mkdir -p ../../build_ablate
 for N in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc -DFQ_PART=2 -DLDPC_FUSED_ABLATE=$N -c fused_inst.hip -o ../../build_ablate/fused_inst_2_abl$N.o &
+  # N = T: the timing build (cycle counters per phase), otherwise an ablation mask
+  if [ "$N" = T ]; then DEF="-DLDPC_FUSED_TIMING=1"; else DEF="-DLDPC_FUSED_ABLATE=$N"; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc -DFQ_PART=2 $DEF -c fused_inst.hip -o ../../build_ablate/fused_inst_2_abl$N.o &
 done
 wait
 for N in "$@"; do
