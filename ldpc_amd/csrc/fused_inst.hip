@@ -10,10 +10,10 @@
 
 namespace ldpc {
 
-template <int CPT, int R2, int SH, bool FRESH = false>
+template <int CPT, int R2, int SH>
 static FusedKern fq_one() {
-  if constexpr (fq_reg_max_block(CPT, R2) == 1024) return fused_q88_reg_kernel<CPT, R2, SH, 1024, 4, FRESH>;
-  else if constexpr (fq_reg_max_block(CPT, R2) == 768) return fused_q88_reg_kernel<CPT, R2, SH, 768, 3, FRESH>;
+  if constexpr (fq_reg_max_block(CPT, R2) == 1024) return fused_q88_reg_kernel<CPT, R2, SH, 1024, 4>;
+  else if constexpr (fq_reg_max_block(CPT, R2) == 768) return fused_q88_reg_kernel<CPT, R2, SH, 768, 3>;
   else return nullptr;
 }
 
@@ -23,9 +23,6 @@ static FusedKern fq_pick(int cpt, int sh) {
     case 1: return fq_one<1, R2, 0>();
     case 2: return fq_one<2, R2, 0>();
     case 3: return fq_one<3, R2, 0>();
-    case 5: return fq_one<1, R2, 0, true>();    // sh = 1: SH = 0, two sum arrays (FRESH)
-    case 6: return fq_one<2, R2, 0, true>();
-    case 7: return fq_one<3, R2, 0, true>();
     case 9: return fq_one<1, R2, 2>();
     case 10: return fq_one<2, R2, 2>();
     case 11: return fq_one<3, R2, 2>();

@@ -373,27 +373,12 @@ __device__ __forceinline__ int fq_block_or(int bad, int *flags, int t) {
   return r;
 }
 
-// FRESH (codes of up to FQ_FRESH_WORDS LDS words, SH = 0): the sums of the next iteration are
-// built afresh, sum' = q0 + (all new messages), in a second array, instead of being moved by
-// (new - old) in place.  Phase B then has nothing to do with the old messages -- per slot one
-// sign injection, one mask shift and one convert go away -- at the price of a copy of q0 in LDS
-// (16 bit, in LDS word order) from which the target array is re-armed during phase A, a linear
-// pass of words / 2 reads per workgroup.  The arrays swap roles every iteration; which one a
-// slot loop reads or adds into is an immediate offset of its DS instructions (the loop body
-// exists once per parity), so the packed 16-bit addresses serve both.
-//   LDS: [0, OFF) sums A | [OFF, 2 OFF) sums B | q0 as int16 [words] | frame id and flags
-#define FQ_FRESH_OFF 65280                    /* bytes between the two arrays (a DS offset immediate) */
-#define FQ_FRESH_WORDS (FQ_FRESH_OFF / 4)
-inline size_t fq_fresh_lds_bytes(int words) { return 2 * (size_t)FQ_FRESH_OFF + (((size_t)words * 2 + 15) & ~(size_t)15) + 16; }
-
 // SH: LDS byte offset = index << SH (0 when the offsets themselves fit 16 bits)
-template <int CPT, int R2, int SH, int LB, int MINW, bool FRESH = false>
+template <int CPT, int R2, int SH, int LB, int MINW>
 __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
-  static_assert(!FRESH || SH == 0, "the two-array build uses absolute 16-bit addresses");
   extern __shared__ __attribute__((aligned(16))) int fsum[];   // [n] + dummies + frame id
   const int tid = threadIdx.x, B = blockDim.x;
-  short *q0s = (short *)((char *)fsum + 2 * FQ_FRESH_OFF);      // (FRESH only)
-  int *frame_slot = FRESH ? (int *)((char *)q0s + ((a.words * 2 + 15) & ~15)) : (int *)(fsum + a.words);
+  int *frame_slot = (int *)(fsum + a.words);
   constexpr int RM = 2 * R2;
   constexpr int CH = RM < 8 ? RM : 8;          // LDS reads in flight per check
   constexpr int NW = (RM + 31) / 32;           // sign-mask words per check
@@ -448,10 +433,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     if (tid == 0) next_frame = atomicAdd(a.counter, 1);
     {
       const size_t base = (size_t)frame * a.n;
-      auto put = [&](int word, int v) {          // one variable's q0 (a value on the Q8.8 grid within int16)
-        fsum[word] = FQ_BIAS + v;
-        if constexpr (FRESH) q0s[word] = (short)v;
-      };
+      auto put = [&](int word, int v) { fsum[word] = FQ_BIAS + v; };   // one variable's q0 (on the Q8.8 grid, within int16)
       if (vec_in) {
         const fq_u4 *p8 = (const fq_u4 *)((const short *)a.llr + base);
         for (int i = tid; i < (a.n >> 3); i += B) {
@@ -461,12 +443,6 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           fsum[w.y & 0xffffu] = FQ_BIAS + (int)(short)(v.y & 0xffffu); fsum[w.y >> 16] = FQ_BIAS + ((int)v.y >> 16);
           fsum[w.z & 0xffffu] = FQ_BIAS + (int)(short)(v.z & 0xffffu); fsum[w.z >> 16] = FQ_BIAS + ((int)v.z >> 16);
           fsum[w.w & 0xffffu] = FQ_BIAS + (int)(short)(v.w & 0xffffu); fsum[w.w >> 16] = FQ_BIAS + ((int)v.w >> 16);
-          if constexpr (FRESH) {
-            q0s[w.x & 0xffffu] = (short)(v.x & 0xffffu); q0s[w.x >> 16] = (short)(v.x >> 16);
-            q0s[w.y & 0xffffu] = (short)(v.y & 0xffffu); q0s[w.y >> 16] = (short)(v.y >> 16);
-            q0s[w.z & 0xffffu] = (short)(v.z & 0xffffu); q0s[w.z >> 16] = (short)(v.z >> 16);
-            q0s[w.w & 0xffffu] = (short)(v.w & 0xffffu); q0s[w.w >> 16] = (short)(v.w >> 16);
-          }
         }
       } else if (a.dt == 2) {
         const short *p = (const short *)a.llr + base;
@@ -485,8 +461,6 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         for (int i = tid; i < a.n; i += B) put(a.pos[i], fq_from_real(p[i]));
       }
       for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // dummies
-      // (FRESH: the few LDS words no variable lives in are copied with the rest when an array is
-      // re-armed; nothing reads them)
     }
     // compressed messages of the previous (o*) and the current (n*) iteration
     float om1[CPT], om2[CPT], nm1[CPT], nm2[CPT];
@@ -511,46 +485,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     FQ_TACC(6, tf_in0, tf_in);
 
     int it_done = a.max_iter, ok = 0;
-    int fin = 0;                               // (FRESH) word offset of the array that holds the final sums
-    // One iteration; PAR (FRESH only) = which array holds the sums it reads.  Returns true when
-    // the frame is finished.
-    auto iteration = [&](auto par_c, const int t) -> bool {
-      constexpr int PAR = decltype(par_c)::value;
-      constexpr int RO = FRESH ? PAR * FQ_FRESH_OFF : 0;          // byte offset of the array read ...
-      constexpr int TO = FRESH ? (1 - PAR) * FQ_FRESH_OFF : 0;    // ... and of the one phase B adds into
-      auto at = [](lds_int *p, auto off_c) { return (lds_int *)((__attribute__((address_space(3))) char *)p + decltype(off_c)::value); };
-      constexpr std::integral_constant<int, RO> ro_c{};
-      constexpr std::integral_constant<int, TO> to_c{};
+    for (int t = 1; t <= a.max_iter + 1; t++) {
       FQ_TICK(tc0);
-      if constexpr (FRESH) {
-        fin = RO / 4;
-        // re-arm the target array: q0 (+ bias) for the variables, the pad value for the dummies.  Its
-        // last readers were the previous iteration's phase A; this iteration's phase B comes after
-        // the barrier below.
-        if (t != a.max_iter + 1) {
-          int *tgt = fsum + TO / 4;
-          // eight variables per 16-byte read, two reads in flight (dummy_base is a multiple of 32)
-          const fq_u4 *q8 = (const fq_u4 *)q0s;
-          fq_u4 *t4 = (fq_u4 *)tgt;
-          const int ng = a.dummy_base >> 3;
-          auto widen = [&](int g, const fq_u4 x) {
-            fq_u4 lo, hi;
-            lo.x = FQ_BIAS + (int)(short)(x.x & 0xffffu); lo.y = FQ_BIAS + ((int)x.x >> 16);
-            lo.z = FQ_BIAS + (int)(short)(x.y & 0xffffu); lo.w = FQ_BIAS + ((int)x.y >> 16);
-            hi.x = FQ_BIAS + (int)(short)(x.z & 0xffffu); hi.y = FQ_BIAS + ((int)x.z >> 16);
-            hi.z = FQ_BIAS + (int)(short)(x.w & 0xffffu); hi.w = FQ_BIAS + ((int)x.w >> 16);
-            t4[2 * g] = lo; t4[2 * g + 1] = hi;
-          };
-          for (int g = tid; g < ng; g += 2 * B) {
-            const bool two = g + B < ng;
-            const fq_u4 x = q8[g];
-            const fq_u4 y = q8[two ? g + B : g];
-            widen(g, x);
-            if (two) widen(g + B, y);
-          }
-          for (int i = a.dummy_base + tid; i < a.words; i += B) tgt[i] = FQ_BIG;
-        }
-      }
       int bad = 0;
       // Phase A for the first NA of the thread's checks.  NA is CPT except in wavefronts whose
       // last round holds no check at all (the rounds fill up in order, so those have exactly
@@ -592,7 +528,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
               if (k >= RM) continue;               // (compile time: last chunk of an RM that CH does not divide)
               if (LDPC_FUSED_ABLATE & 2) S[r][j] = (int)(unsigned)(unsigned long)((k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]));
               else
-              S[r][j] = (k & 1) ? *at(fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]), ro_c) : *at(fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]), ro_c);
+              S[r][j] = (k & 1) ? *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
             }
 #pragma unroll
           for (int j = 0; j < CH; j++)
@@ -673,8 +609,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           unsigned pp = 0;
 #pragma unroll
           for (int k = 0; k < RM; k += 2) {
-            const int s0 = *at(fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]), ro_c) - FQ_BIAS;
-            const int s1 = *at(fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]), ro_c) - FQ_BIAS;
+            const int s0 = *fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]) - FQ_BIAS;
+            const int s1 = *fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) - FQ_BIAS;
             pp = __builtin_amdgcn_bitop3_b32(pp, (unsigned)s0, (unsigned)s1, 0x96);
           }
           par[r] = (int)(pp >> 31);
@@ -691,10 +627,9 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       FQ_TICK(tc2);
       FQ_TACC(0, tc0, tc1);
       FQ_TACC(1, tc1, tc2);
-      if (!any_bad) { it_done = t - 1; ok = 1; return true; }
-      if (t == a.max_iter + 1) return true;
-      if constexpr (!FRESH)
-        for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
+      if (!any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (races only with this phase's bounded adds)
       // ---- phase B.  delta_k = c_new_k - c_old_k with c = +-min1 everywhere except in the
       // slot of min1 itself, where it is +-min2.  The slot loop treats every slot as
       // "+-min1" (integer arithmetic on sign masks, no per-slot selects) and the two
@@ -713,16 +648,12 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           for (int w = 0; w < NW; w++) { nrot[w] = nsg[r][w] << (32 - WB); prot[w] = osg[r][w] << (32 - WB); }
 #pragma unroll
           for (int k = 0; k < RM; k++) {
-            lds_int *dst = at((k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]), to_c);
+            lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
             const float cn = __uint_as_float(FQ_ANDOR(nrot[k / 32], 0x80000000u, __float_as_uint(nm1[r])));
+            const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
             nrot[k / 32] = fq_shl1(nrot[k / 32]);
-            float d = cn;                        // FRESH: the target array starts from q0, the new message goes in whole
-            if constexpr (!FRESH) {
-              const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
-              prot[k / 32] = fq_shl1(prot[k / 32]);
-              d = cn - co;
-            }
-            const int delta = (LDPC_FUSED_ABLATE & 128) ? (int)__float_as_uint(d) : (int)d;
+            prot[k / 32] = fq_shl1(prot[k / 32]);
+            const int delta = (LDPC_FUSED_ABLATE & 128) ? (int)__float_as_uint(cn - co) : (int)(cn - co);
             if (LDPC_FUSED_ABLATE & 1) asm volatile("" ::"v"(delta), "v"(dst));
             else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -734,8 +665,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             const unsigned ao = oarg[r], an = narg[r];   // < RM: a real slot always wins the minimum
             const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
             const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
-            if constexpr (!FRESH) atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
-            atomicAdd((int *)(lds + noff[r] + TO), (dmn ^ sn) - sn);
+            atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
+            atomicAdd((int *)(lds + noff[r]), (dmn ^ sn) - sn);
           }
           om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
 #pragma unroll
@@ -749,15 +680,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       FQ_TICK(tc4);
       FQ_TACC(2, tc2, tc3);
       FQ_TACC(3, tc3, tc4);
-      return false;
-    };
-    for (int t = 1; t <= a.max_iter + 1; t++) {
-      bool finished;
-      if (FRESH && !(t & 1) && !(LDPC_FUSED_ABLATE & 1024)) finished = iteration(std::integral_constant<int, 1>{}, t);
-      else finished = iteration(std::integral_constant<int, 0>{}, t);
-      if (finished) break;
     }
-    const int *sums = fsum + fin;              // where the final sums are
     FQ_TICK(tf_out0);
 
     if (vec_out) {
@@ -765,19 +688,19 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       for (int i = tid; i < (a.n >> 3); i += B) {
         const fq_u4 w = pos8[i];
         fq_u2 b;
-        auto neg = [&](unsigned word) { return (unsigned)(sums[word] - FQ_BIAS) >> 31; };
+        auto neg = [&](unsigned word) { return (unsigned)(fsum[word] - FQ_BIAS) >> 31; };
         b.x = neg(w.x & 0xffffu) | (neg(w.x >> 16) << 8) | (neg(w.y & 0xffffu) << 16) | (neg(w.y >> 16) << 24);
         b.y = neg(w.z & 0xffffu) | (neg(w.z >> 16) << 8) | (neg(w.w & 0xffffu) << 16) | (neg(w.w >> 16) << 24);
         __builtin_nontemporal_store(b, o8 + i);
       }
     } else if (a.bits) {
       uint8_t *o = a.bits + (size_t)frame * a.n;
-      for (int i = tid; i < a.n; i += B) o[i] = sums[a.pos[i]] < FQ_BIAS;
+      for (int i = tid; i < a.n; i += B) o[i] = fsum[a.pos[i]] < FQ_BIAS;
     }
     if (a.llr_out) {
       float *o = a.llr_out + (size_t)frame * a.n;
       for (int i = tid; i < a.n; i += B) {
-        int s = sums[a.pos[i]] - FQ_BIAS;
+        int s = fsum[a.pos[i]] - FQ_BIAS;
         s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);   // float_to_fix(sum), :303
         o[i] = (float)s * (1.0f / 256.0f);
       }

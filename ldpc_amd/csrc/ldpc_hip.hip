@@ -659,7 +659,7 @@ struct FusedQ88Engine : Engine {
   size_t lds = 0;
   DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT, d_timing;
   LdsSchedule sched;
-  bool use_reg = false, fresh = false;
+  bool use_reg = false;
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
@@ -770,18 +770,6 @@ struct FusedQ88Engine : Engine {
         small = (size_t)(sched.words - 1) * 4 + fa.sharedSizeBytes <= 65535;
       }
       if (!small) kern = fused_reg_lookup(rounds, r2, 2);
-      // two sum arrays + q0 in LDS (phase B without the old messages) where they fit next to
-      // the workgroups that share the CU
-      int want_fresh = 1;
-      if (const char *e = getenv("LDPC_HIP_FUSED_FRESH")) want_fresh = atoi(e);
-      if (small && want_fresh && sched.words <= FQ_FRESH_WORDS &&
-          (size_t)wg_per_cu * fq_fresh_lds_bytes(sched.words) <= 160 * 1024) {
-        if (FusedKern k2 = fused_reg_lookup(rounds, r2, 1)) {
-          hipFuncAttributes fa;
-          HIPCHK(hipFuncGetAttributes(&fa, (const void *)k2));
-          if (fa.sharedSizeBytes == 0) { kern = k2; fresh = true; lds = fq_fresh_lds_bytes(sched.words); }
-        }
-      }
       if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
       if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
       if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
@@ -822,7 +810,7 @@ struct FusedQ88Engine : Engine {
     if ((rc = d_counter.ensure(256))) return rc;
     if (getenv("LDPC_HIP_VERBOSE"))
       fprintf(stderr, "ldpc_hip: fused Q8.8 decoder: %d threads x %d workgroup(s) per CU, %d check(s) per thread, %s, %zu B LDS\n",
-              block, wg_per_cu, rounds, !use_reg ? "generic kernel" : fresh ? "register-cached kernel, two sum arrays" : "register-cached kernel", lds);
+              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : "generic kernel", lds);
     return LDPC_OK;
   }
 
