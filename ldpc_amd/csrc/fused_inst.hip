@@ -26,9 +26,6 @@ static FusedKern fq_pick(int cpt, int sh) {
     case 9: return fq_one<1, R2, 2>();
     case 10: return fq_one<2, R2, 2>();
     case 11: return fq_one<3, R2, 2>();
-    case 14:                                    // sh = 3: SH = 0 with the odd unit split over quads (QS)
-      if constexpr (R2 % 4 == 0 && R2 <= 16) return fused_q88_reg_kernel<2, R2, 0, 1024, 4, true>;
-      break;
   }
   return nullptr;
 }

@@ -60,8 +60,6 @@ struct FusedArgs {
   int words, dummy_base, ndummy;
   // timing builds only (LDPC_FUSED_TIMING, tools/probes): [16 wavefronts][8] cycle sums
   unsigned long long *timing;
-  // QS kernels: which 64-thread unit of round 1 is split over the wavefronts 12..15 (below)
-  int qs_unit;
 };
 
 typedef void (*FusedKern)(FusedArgs);
@@ -375,39 +373,13 @@ __device__ __forceinline__ int fq_block_or(int bad, int *flags, int t) {
   return r;
 }
 
-// QS ("quad split", 16 wavefronts with two rounds): the four SIMDs of a CU each run four of the
-// wavefronts, and the pace of an iteration is set by the SIMD with the most 64-check units.  With
-// U units, U = 1 mod 4, the split is 7/6/6/6 (PEG-16000: 25 units) -- one unit too many on one
-// SIMD, 12 % of the iteration.  The QS kernels cut that unit four ways instead: each of the
-// wavefronts 12..15 (one per SIMD, one unit of their own each) takes 16 of its checks, four lanes
-// per check, RM / 4 slots per lane; the four partial results (two smallest keys, sign parity,
-// hard-decision parity) are merged inside the quad with two DPP exchanges, so every lane of the
-// quad ends up with the check's whole compressed state and nothing crosses a wavefront.  All
-// SIMDs then carry U / 4 units.  (The placement makes slot k conflict free across the 32 checks
-// of a half wave; a quad reads four different slots, so these reads and adds can collide --
-// 1/25th of the LDS traffic.)
-template <unsigned CTRL>
-__device__ __forceinline__ unsigned fq_quad(unsigned x) {   // x of another lane of the quad (DPP quad_perm)
-  return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true);
-}
-#define FQ_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */
-#define FQ_QUAD_XOR2 0x4E /* quad_perm [2,3,0,1] */
-
 // SH: LDS byte offset = index << SH (0 when the offsets themselves fit 16 bits)
-template <int CPT, int R2, int SH, int LB, int MINW, bool QS = false>
+template <int CPT, int R2, int SH, int LB, int MINW>
 __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
-  static_assert(!QS || (CPT == 2 && LB == 1024 && R2 % 4 == 0 && R2 <= 16), "quad split: two rounds, 16 wavefronts, one mask word");
   extern __shared__ __attribute__((aligned(16))) int fsum[];   // [n] + dummies + frame id
   const int tid = threadIdx.x, B = blockDim.x;
   int *frame_slot = (int *)(fsum + a.words);
   constexpr int RM = 2 * R2;
-  constexpr int RMQ = RM / 4;                  // (QS) slots per lane of a quad
-  // (QS) wavefronts 12..15: lane l works on check 64 qs_unit + 16 (wave - 12) + l / 4 of round 1,
-  // slots [RMQ (l % 4), RMQ (l % 4 + 1))
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (wave-uniform, and known to be)
-  const bool qwave = QS && wave >= 12;
-  const unsigned qoff = (unsigned)(tid & 3) * RMQ;
-  const int t1 = qwave ? 64 * a.qs_unit + 16 * (wave - 12) + ((tid & 63) >> 2) : tid;   // thread slot of the round-1 check
   constexpr int CH = RM < 8 ? RM : 8;          // LDS reads in flight per check
   constexpr int NW = (RM + 31) / 32;           // sign-mask words per check
   constexpr int WB = RM < 32 ? RM : 32;        // slots per mask word
@@ -421,38 +393,24 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
   unsigned allm[CPT][NW];                      // mask bits of the real slots
 #pragma unroll
   for (int r = 0; r < CPT; r++) {
-    // (QS) in round 1 the split unit and everything after it belong to no ordinary wavefront
-    const bool mine = r < a.rounds && !(QS && r == 1 && !qwave && wave >= a.qs_unit);
-    const int tr = (QS && r == 1) ? t1 : tid;
-    dc[r] = mine ? a.dcT[r * B + tr] : 0;
+    dc[r] = r < a.rounds ? a.dcT[r * B + tid] : 0;
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) {
       unsigned lo = (unsigned)a.dummy_base, hi = (unsigned)a.dummy_base;
-      if (mine) {
-        const uint16_t *col = a.colT + (size_t)r * RM * B + tr;
-        // (a quad lane holds its RMQ slots in the first RMQ / 2 registers)
-        const int k0 = (QS && r == 1 && qwave) ? (int)qoff + (2 * k2) % RMQ : 2 * k2;
-        lo = col[(size_t)k0 * B];
-        hi = col[(size_t)(k0 + 1) * B];
+      if (r < a.rounds) {
+        const uint16_t *col = a.colT + (size_t)r * RM * B + tid;
+        lo = col[(size_t)(2 * k2) * B];
+        hi = col[(size_t)(2 * k2 + 1) * B];
       }
       if (SH == 0) { lo = lo * 4u + lbase; hi = hi * 4u + lbase; }   // absolute addresses (host: words*4 + static LDS < 64 Ki)
       idx[r][k2] = lo | (hi << 16);
     }
 #pragma unroll
-    for (int w = 0; w < NW; w++) allm[r][w] = mine ? a.maskT[((size_t)r * B + tr) * NW + w] : 0u;
-    // (quad lane: the mask bits of its own slots, right-aligned like a whole mask of RMQ slots)
-    if (QS && r == 1 && qwave) allm[r][0] = (allm[r][0] >> (RM - RMQ - (int)qoff)) & ((1u << RMQ) - 1u);
+    for (int w = 0; w < NW; w++) allm[r][w] = r < a.rounds ? a.maskT[((size_t)r * B + tid) * NW + w] : 0u;
   }
 
-  // does this wavefront own any check of the last round?  (wave-uniform; the quad wavefronts
-  // run their round-1 share through code of its own)
-  const bool wave_full = !qwave && __ballot(dc[CPT - 1] != 0) != 0;
-#ifndef LDPC_FUSED_PRIO
-#define LDPC_FUSED_PRIO 0
-#endif
-  // issue priority (experiment): the arbiter prefers older wavefronts, so the youngest one is left to
-  // finish a phase on its own
-  if (LDPC_FUSED_PRIO >= 1 && !wave_full) __builtin_amdgcn_s_setprio(3);
+  // does this wavefront own any check of the last round?  (wave-uniform)
+  const bool wave_full = __ballot(dc[CPT - 1] != 0) != 0;
 
   // 8 variables per thread and step on the way in (int16 LLRs) and out (bits): needs
   // 16-byte aligned frames / 8-byte aligned bit rows
@@ -516,7 +474,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       ooff[r] = noff[r] = (unsigned)a.dummy_base * 4u;
 #pragma unroll
       for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w] = 0;
-      sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + r * B + ((QS && r == 1) ? t1 : tid)] & 1) : 0;
+      sbit[r] = (a.synd && dc[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
       par[r] = 0;
     }
     if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
@@ -561,10 +519,6 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         // reads in flight and CPT independent min chains
 #pragma unroll
         for (int kc = 0; kc < RM; kc += CH) {
-          if (LDPC_FUSED_PRIO >= 2 && NA == CPT) {
-            if ((((kc / CH) ^ (tid >> 8)) & 1) != 0) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(0);
-          }
           int S[CPT][CH];
 #pragma unroll
           for (int r = 0; r < NA; r++)
@@ -663,93 +617,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           bad |= par[r] ^ sbit[r];
         }
       };
-      // (QS) the round-1 share of a quad wavefront: RMQ slots of the lane's check, then the merge
-      // across the quad; leaves the same compressed state in [1] as phase_a does
-      auto quad_slot = [&](int kk) -> lds_int * {
-        return (kk & 1) ? fq_slot_ptr<1, SH>(lbase, idx[1][kk >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[1][kk >> 1]);
-      };
-      auto quad_parity = [&](unsigned pp) {      // hard-decision parity of the whole check from the lanes' shares
-        pp ^= fq_quad<FQ_QUAD_XOR1>(pp);
-        pp ^= fq_quad<FQ_QUAD_XOR2>(pp);
-        par[1] = (int)(pp >> 31);
-        bad |= par[1] ^ sbit[1];
-      };
-      auto phase_a_quad = [&]() {
-        constexpr int r = 1;
-        const unsigned oloc = oarg[r] - qoff;      // the previous minimum's slot, counted within this lane's share
-        unsigned long long ab[3];
-#pragma unroll
-        for (int b = 0; b < 3; b++) ab[b] = __ballot((oloc >> b) & 1u);
-        const unsigned long long own = __ballot(oloc < (unsigned)RMQ);
-        unsigned k1 = 0xffffffffu, k2m = 0xffffffffu, pp = 0;
-        unsigned sg = osg[r][0] << (32 - RMQ);
-        int S[RMQ];
-#pragma unroll
-        for (int kk = 0; kk < RMQ; kk++) S[kk] = *quad_slot(kk);
-#pragma unroll
-        for (int kk = 0; kk < RMQ; kk++) {
-          if ((kk & 1) == 0) {
-            S[kk] = (int)__float_as_uint(__uint_as_float((unsigned)S[kk]) - FQ_BIASF);
-            S[kk + 1] = (int)__float_as_uint(__uint_as_float((unsigned)S[kk + 1]) - FQ_BIASF);
-            pp = __builtin_amdgcn_bitop3_b32(pp, (unsigned)S[kk], (unsigned)S[kk + 1], 0x96);
-          }
-          unsigned long long in_k = own;
-#pragma unroll
-          for (int b = 0; b < 3; b++) in_k &= ((kk >> b) & 1) ? ab[b] : ~ab[b];
-          float mo;
-          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
-          const float q = __uint_as_float((unsigned)S[kk]) - __uint_as_float(FQ_ANDOR(sg, 0x80000000u, __float_as_uint(mo)));
-          sg = __builtin_amdgcn_alignbit(sg, __float_as_uint(q), 31);
-          const unsigned key = FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)kk);
-          k2m = fq_med3u(k1, key, k2m);
-          k1 = min(k1, key);
-        }
-        // slot numbers of the whole check (no carry: kk + qoff < RM <= 32 and the low KB bits held kk)
-        k1 += qoff;
-        k2m += qoff;
-        unsigned sp = (unsigned)__popc(sg);
-        {
-          unsigned o1 = fq_quad<FQ_QUAD_XOR1>(k1), o2 = fq_quad<FQ_QUAD_XOR1>(k2m);
-          k2m = min(max(k1, o1), min(k2m, o2));
-          k1 = min(k1, o1);
-          sp ^= fq_quad<FQ_QUAD_XOR1>(sp);
-          o1 = fq_quad<FQ_QUAD_XOR2>(k1); o2 = fq_quad<FQ_QUAD_XOR2>(k2m);
-          k2m = min(max(k1, o1), min(k2m, o2));
-          k1 = min(k1, o1);
-          sp ^= fq_quad<FQ_QUAD_XOR2>(sp);
-        }
-        quad_parity(pp);
-        const unsigned tot = ((unsigned)sbit[r] ^ sp) & 1u;
-        nm1[r] = fq_finish_minf(__uint_as_float(k1 & ~KM));
-        nm2[r] = fq_finish_minf(__uint_as_float(k2m & ~KM));
-        narg[r] = min(k1 & KM, (unsigned)(RM - 1));
-        {
-          const uint16_t *ct = a.colT;
-          asm volatile("" : "+s"(ct));
-          noff[r] = (unsigned)ct[((size_t)RM + narg[r]) * B + t1] * 4u;
-        }
-        nsg[r][0] = tot ? (sg ^ allm[r][0]) : sg;
-        asm volatile("" : "+v"(nm1[r]), "+v"(nm2[r]), "+v"(narg[r]), "+v"(nsg[r][0]));
-      };
-      auto parity_only_quad = [&]() {
-        unsigned pp = 0;
-#pragma unroll
-        for (int kk = 0; kk < RMQ; kk += 2) {
-          const int s0 = *quad_slot(kk) - FQ_BIAS;
-          const int s1 = *quad_slot(kk + 1) - FQ_BIAS;
-          pp = __builtin_amdgcn_bitop3_b32(pp, (unsigned)s0, (unsigned)s1, 0x96);
-        }
-        quad_parity(pp);
-      };
       if (t == a.max_iter + 1) {
         if (wave_full) parity_only(std::integral_constant<int, CPT>{});
         else parity_only(std::integral_constant<int, CPT - 1>{});
-        if constexpr (QS) if (qwave) parity_only_quad();
-      } else {
-        if (wave_full) phase_a(std::integral_constant<int, CPT>{});
-        else phase_a(std::integral_constant<int, CPT - 1>{});
-        if constexpr (QS) if (qwave) phase_a_quad();
-      }
+      } else if (wave_full) phase_a(std::integral_constant<int, CPT>{});
+      else phase_a(std::integral_constant<int, CPT - 1>{});
       FQ_TICK(tc1);
       const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : fq_block_or(bad, frame_slot + 1, t);
       FQ_TICK(tc2);
@@ -786,10 +658,6 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
-            if (LDPC_FUSED_PRIO >= 2 && NA == CPT && (k & 7) == 7) {
-              if ((((k >> 3) ^ r ^ (tid >> 8)) & 1) != 0) __builtin_amdgcn_s_setprio(2);
-              else __builtin_amdgcn_s_setprio(0);
-            }
           }
           {
             // slot oarg really carried +-min2 before; slot narg carries +-min2 now
@@ -807,30 +675,6 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       };
       if (wave_full) phase_b(std::integral_constant<int, CPT>{});
       else phase_b(std::integral_constant<int, CPT - 1>{});
-      if constexpr (QS) if (qwave) {
-        // phase B of the lane's share; the two exceptional slots are put right by the lane that holds them
-        constexpr int r = 1;
-        asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]), "+v"(osg[r][0]), "+v"(nsg[r][0]));
-        const int m1o = (int)om1[r], m1n = (int)nm1[r];
-        unsigned nrot = nsg[r][0] << (32 - RMQ), prot = osg[r][0] << (32 - RMQ);
-#pragma unroll
-        for (int kk = 0; kk < RMQ; kk++) {
-          lds_int *dst = quad_slot(kk);
-          const float cn = __uint_as_float(FQ_ANDOR(nrot, 0x80000000u, __float_as_uint(nm1[r])));
-          const float co = __uint_as_float(FQ_ANDOR(prot, 0x80000000u, __float_as_uint(om1[r])));
-          nrot = fq_shl1(nrot);
-          prot = fq_shl1(prot);
-          __hip_atomic_fetch_add(dst, (int)(cn - co), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        const int dmo = (int)om2[r] - m1o, dmn = (int)nm2[r] - m1n;
-        const unsigned lo = oarg[r] - qoff, ln = narg[r] - qoff;
-        const int so = -(int)((osg[r][0] >> ((RMQ - 1 - lo) & 31u)) & 1u);
-        const int sn = -(int)((nsg[r][0] >> ((RMQ - 1 - ln) & 31u)) & 1u);
-        atomicAdd((int *)(lds + ooff[r]), lo < (unsigned)RMQ ? -((dmo ^ so) - so) : 0);
-        atomicAdd((int *)(lds + noff[r]), ln < (unsigned)RMQ ? (dmn ^ sn) - sn : 0);
-        om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
-        osg[r][0] = nsg[r][0];
-      }
       FQ_TICK(tc3);
       if (!(LDPC_FUSED_ABLATE & 4)) __syncthreads();
       FQ_TICK(tc4);
@@ -864,7 +708,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     if (a.sout) {
 #pragma unroll
       for (int r = 0; r < CPT; r++)
-        if (dc[r] && !(QS && r == 1 && qwave && (tid & 3))) a.sout[(size_t)frame * a.m + r * B + ((QS && r == 1) ? t1 : tid)] = (uint8_t)par[r];
+        if (dc[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
     }
     if (tid == 0) {
       if (a.iters) a.iters[frame] = it_done;

@@ -660,7 +660,6 @@ struct FusedQ88Engine : Engine {
   DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT, d_timing;
   LdsSchedule sched;
   bool use_reg = false;
-  int qs_unit = -1;
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
@@ -771,14 +770,6 @@ struct FusedQ88Engine : Engine {
         small = (size_t)(sched.words - 1) * 4 + fa.sharedSizeBytes <= 65535;
       }
       if (!small) kern = fused_reg_lookup(rounds, r2, 2);
-      // 16 wavefronts, two rounds and one 64-check unit more than a multiple of four: that unit is
-      // split four ways so that every SIMD carries the same load (fused_kernels.hip.h, QS)
-      qs_unit = -1;
-      int want_qs = 1;
-      if (const char *e = getenv("LDPC_HIP_FUSED_QSPLIT")) want_qs = atoi(e);
-      if (small && want_qs && block == 1024 && rounds == 2 && r2 % 4 == 0 && r2 <= 16 && (need - 16) % 4 == 1 && need - 17 <= 12) {
-        if (FusedKern k2 = fused_reg_lookup(rounds, r2, 3)) { kern = k2; qs_unit = need - 17; }
-      }
       if ((rc = d_colT.ensure(sched.colT.size() * 2))) return rc;
       if ((rc = d_dcT.ensure(sched.dcT.size()))) return rc;
       if ((rc = d_pos.ensure(sched.pos.size() * 2))) return rc;
@@ -819,7 +810,7 @@ struct FusedQ88Engine : Engine {
     if ((rc = d_counter.ensure(256))) return rc;
     if (getenv("LDPC_HIP_VERBOSE"))
       fprintf(stderr, "ldpc_hip: fused Q8.8 decoder: %d threads x %d workgroup(s) per CU, %d check(s) per thread, %s, %zu B LDS\n",
-              block, wg_per_cu, rounds, !use_reg ? "generic kernel" : qs_unit >= 0 ? "register-cached kernel, odd unit split over quads" : "register-cached kernel", lds);
+              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : "generic kernel", lds);
     return LDPC_OK;
   }
 
@@ -845,7 +836,6 @@ struct FusedQ88Engine : Engine {
     a.maskT = d_maskT.as<uint32_t>();
     a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
     a.timing = nullptr;
-    a.qs_unit = qs_unit;
     const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;   // (only timing builds of the kernel write it)
     if (timing) {
       if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
