@@ -66,9 +66,6 @@ struct FfArgs {
   void *q0g;
 };
 
-#ifndef FF_ONEHOT
-#define FF_ONEHOT 0   /* 1: old-minimum slot by a rotating one-hot mask instead of a compare per slot */
-#endif
 #define FF_NDUMMY 64
 #define FF_CAP 200          /* min_msg starts at 200 (test_code_min_sum_B.c:169) */
 
@@ -414,13 +411,22 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
       auto check_pass = [&](auto na_c) {
         constexpr int NA = decltype(na_c)::value;
         float m1[CPT], m2[CPT];
-        unsigned arg[CPT], pp[CPT], sg[CPT], orot[CPT], oarot[CPT];
+        unsigned arg[CPT], pp[CPT], sg[CPT];
+        // The slot of the previous minimum, transposed: one lane mask per bit, in scalar registers.
+        // Which lanes read min2 in slot k is then an AND on the scalar unit, not a vector compare
+        // per slot.  (The running minimum's slot stays in a vector register: tracking it the same
+        // way costs five scalar operations per slot, and the CU's one scalar unit issues no faster
+        // than its vector units -- measured 43.9 against 47.0 Gbit/s.)
+        unsigned long long ob[CPT][5];
 #pragma unroll
         for (int r = 0; r < NA; r++) {
           m1[r] = m2[r] = (float)FF_CAP;
-          arg[r] = 0u; pp[r] = 0u; sg[r] = 0u;
-          orot[r] = osg[r] << (32 - RM);           // old sign of the slot in turn: always bit 31
-          oarot[r] = 0x80000000u >> oarg[r];
+          pp[r] = 0u; arg[r] = 0u;
+          // one register serves both sign masks: the old signs leave at the top (the slot in turn is
+          // always bit 31) while the new ones enter at the bottom, one v_alignbit per slot
+          sg[r] = osg[r] << (32 - RM);
+#pragma unroll
+          for (int b = 0; b < 5; b++) ob[r][b] = __ballot((oarg[r] >> b) & 1u);
         }
 #pragma unroll
         for (int kc = 0; kc < RM; kc += CH) {
@@ -442,15 +448,12 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
               // parity of the hard decisions (sums are stored as sum + 0.0: sign bit <=> sum < 0)
               if ((j & 1) == 0) pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
               // old magnitude of this slot: min2 in the slot of min1 (its one-hot mask rotates with the signs)
-#if FF_ONEHOT
-              const unsigned sel = (unsigned)((int)oarot[r] >> 31);
-              oarot[r] = fq_shl1(oarot[r]);
-              const float mo = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(om2[r]), __float_as_uint(om1[r]), 0xCA));
-#else
-              const float mo = ((unsigned)k == oarg[r]) ? om2[r] : om1[r];
-#endif
-              const float q = __int_as_float(S[r][j]) - __uint_as_float(FQ_ANDOR(orot[r], 0x80000000u, __float_as_uint(mo)));
-              orot[r] = fq_shl1(orot[r]);
+              unsigned long long in_k = (k & 1) ? ob[r][0] : ~ob[r][0];
+#pragma unroll
+              for (int b = 1; b < 5; b++) in_k &= ((k >> b) & 1) ? ob[r][b] : ~ob[r][b];
+              float mo;
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
+              const float q = __int_as_float(S[r][j]) - __uint_as_float(FQ_ANDOR(sg[r], 0x80000000u, __float_as_uint(mo)));
               sg[r] = __builtin_amdgcn_alignbit(sg[r], __float_as_uint(q), 31);
               const float aq = __builtin_fabsf(q);
               m2[r] = __builtin_amdgcn_fmed3f(m1[r], aq, m2[r]);
@@ -463,11 +466,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
           // up after the last chunk with every sum it read still live
 #pragma unroll
           for (int r = 0; r < NA; r++)
-#if FF_ONEHOT
-            asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]), "+v"(orot[r]), "+v"(oarot[r]));
-#else
-            asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]), "+v"(orot[r]));
-#endif
+            asm volatile("" : "+v"(pp[r]), "+v"(m1[r]), "+v"(m2[r]), "+v"(arg[r]), "+v"(sg[r]));
           __builtin_amdgcn_sched_barrier(0);   // keeps a chunk's work in the chunk (live registers)
         }
 #pragma unroll
