@@ -110,7 +110,19 @@ typedef struct ldpc_opts {
                            0: always run max_iter iterations (no host sync inside)      */
   int32_t want_llr;     /* 1: keep posterior LLRs so llr_out can be filled              */
   int32_t cn_variant;   /* 0 = default; kernel selection knob for benchmarking          */
-  int32_t reserved[10];
+  int32_t layer_checks; /* 0: the reference's flooding schedule.  L > 0 (MINSUM_Q88, frames
+                           that fit LDS; L a multiple of 64, m/8 <= L <= 1024): layered
+                           schedule -- an iteration walks the checks in layers of L
+                           consecutive rows; the checks of a layer read the sums as the
+                           previous layer left them and their new messages replace the old
+                           ones in the sums before the next layer reads.  Every message is
+                           computed as dec() computes it (test_code_min_sum_B_fixed.c:213-283);
+                           pre-check and exit test are dec()'s (:198-207, :298-313).  An
+                           alternative schedule with NO counterpart in the
+                           reference: results differ from dec()'s by design (it converges
+                           in fewer iterations); checked bit for bit against
+                           oracle/ldpc_oracle.c ora_dec_minsum_fixed_layered().          */
+  int32_t reserved[9];
 } ldpc_opts;
 
 typedef struct ldpc_decoder ldpc_decoder;

@@ -60,6 +60,8 @@ struct FusedArgs {
   int words, dummy_base, ndummy;
   // timing builds only (LDPC_FUSED_TIMING, tools/probes): [16 wavefronts][8] cycle sums
   unsigned long long *timing;
+  // generic kernel only: 1 = layered schedule, one layer = one round (blockDim.x consecutive checks)
+  int layered;
 };
 
 typedef void (*FusedKern)(FusedArgs);
@@ -193,38 +195,81 @@ __global__ __launch_bounds__(1024) void fused_q88_kernel(FusedArgs a) {
     __syncthreads();
 
     int it_done = a.max_iter, ok = 0;
+    // check pass of the thread's check of round r on the sums as they stand: new compressed
+    // messages into nxt[r]; returns the parity of the hard decisions of its variables
+    auto check_round = [&](const int r) -> int {
+      const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+      const int d = dc[r];
+      int m1 = FQ_CAP, m2 = FQ_CAP, arg = -1, p = 0;
+      MaskT sg = 0;
+      for (int k = 0; k < d; k++) {
+        const int v = col[(size_t)k * B];
+        const int S = sum[v];
+        p ^= (S < 0);
+        const int q = S - cs_msg(cur[r], k);
+        const int neg = q < 0;
+        int mag = neg ? -q : q;
+        mag = mag > FQ_SAT ? FQ_SAT : mag;
+        sg |= (MaskT)neg << k;
+        if (mag < m1) { m2 = m1; m1 = mag; arg = k; }
+        else if (mag < m2) { m2 = mag; }
+      }
+      // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
+      int tot = sbit[r];
+      if (sizeof(MaskT) == 8) tot ^= __popcll((unsigned long long)sg) & 1;
+      else tot ^= __popc((unsigned)sg) & 1;
+      MaskT all = d >= (int)(8 * sizeof(MaskT)) ? ~(MaskT)0 : (((MaskT)1 << d) - 1);
+      nxt[r].mins = (unsigned)m1 | ((unsigned)m2 << 16);
+      nxt[r].arg = arg;
+      nxt[r].sg = tot ? (sg ^ all) : sg;
+      return p;
+    };
+    // the new messages of round r replace the old ones in the sums
+    auto fold_round = [&](const int r) {
+      const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+      const int d = dc[r];
+      for (int k = 0; k < d; k++) {
+        const int delta = cs_msg(nxt[r], k) - cs_msg(cur[r], k);
+        if (delta) atomicAdd(&sum[col[(size_t)k * B]], delta);
+      }
+      cur[r] = nxt[r];
+    };
     for (int t = 1; t <= a.max_iter + 1; t++) {
-      // ---- phase A: check pass on the sums of iteration t-1
       int bad = 0;
+      if (a.layered) {
+        // ---- layered schedule (ldpc_opts.layer_checks; not in the reference): the exit test on the
+        // sums of iteration t-1 first (dec()'s, :298-313), then layer after layer
+#pragma unroll
+        for (int r = 0; r < CPT; r++) {
+          if (r < a.rounds) {
+            const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
+            int p = 0;
+            for (int k = 0; k < dc[r]; k++) p ^= (sum[col[(size_t)k * B]] < 0);
+            par[r] = p;
+            bad |= p ^ sbit[r];
+          }
+        }
+        const int any_bad = __syncthreads_or(bad);
+        if (!any_bad) { it_done = t - 1; ok = 1; break; }
+        if (t == a.max_iter + 1) break;
+#pragma unroll
+        for (int r = 0; r < CPT; r++) {
+          if (r < a.rounds) {                      // (uniform: every thread takes part in the barriers)
+            (void)check_round(r);
+            __syncthreads();                       // the whole layer has read its sums
+            fold_round(r);
+            __syncthreads();
+          }
+        }
+        continue;
+      }
+      // ---- phase A: check pass on the sums of iteration t-1
 #pragma unroll
       for (int r = 0; r < CPT; r++) {
         if (r < a.rounds) {
-          const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
-          const int d = dc[r];
-          int m1 = FQ_CAP, m2 = FQ_CAP, arg = -1, p = 0;
-          MaskT sg = 0;
-          for (int k = 0; k < d; k++) {
-            const int v = col[(size_t)k * B];
-            const int S = sum[v];
-            p ^= (S < 0);
-            const int q = S - cs_msg(cur[r], k);
-            const int neg = q < 0;
-            int mag = neg ? -q : q;
-            mag = mag > FQ_SAT ? FQ_SAT : mag;
-            sg |= (MaskT)neg << k;
-            if (mag < m1) { m2 = m1; m1 = mag; arg = k; }
-            else if (mag < m2) { m2 = mag; }
-          }
+          const int p = check_round(r);
           par[r] = p;
           bad |= p ^ sbit[r];
-          // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
-          int tot = sbit[r];
-          if (sizeof(MaskT) == 8) tot ^= __popcll((unsigned long long)sg) & 1;
-          else tot ^= __popc((unsigned)sg) & 1;
-          MaskT all = d >= (int)(8 * sizeof(MaskT)) ? ~(MaskT)0 : (((MaskT)1 << d) - 1);
-          nxt[r].mins = (unsigned)m1 | ((unsigned)m2 << 16);
-          nxt[r].arg = arg;
-          nxt[r].sg = tot ? (sg ^ all) : sg;
         }
       }
       const int any_bad = __syncthreads_or(bad);
@@ -232,17 +277,8 @@ __global__ __launch_bounds__(1024) void fused_q88_kernel(FusedArgs a) {
       if (t == a.max_iter + 1) break;
       // ---- phase B: fold the new messages into the sums
 #pragma unroll
-      for (int r = 0; r < CPT; r++) {
-        if (r < a.rounds) {
-          const uint16_t *col = a.colT + (size_t)r * a.rmax * B + tid;
-          const int d = dc[r];
-          for (int k = 0; k < d; k++) {
-            const int delta = cs_msg(nxt[r], k) - cs_msg(cur[r], k);
-            if (delta) atomicAdd(&sum[col[(size_t)k * B]], delta);
-          }
-          cur[r] = nxt[r];
-        }
-      }
+      for (int r = 0; r < CPT; r++)
+        if (r < a.rounds) fold_round(r);
       __syncthreads();
     }
 

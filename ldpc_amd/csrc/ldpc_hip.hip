@@ -659,7 +659,7 @@ struct FusedQ88Engine : Engine {
   size_t lds = 0;
   DevBuf d_colT, d_dcT, d_counter, d_pos, d_maskT, d_timing;
   LdsSchedule sched;
-  bool use_reg = false;
+  bool use_reg = false, layered = false;
   void (*kern)(FusedArgs) = nullptr;
 
   static bool fits(const ldpc_code &c) {
@@ -716,6 +716,19 @@ struct FusedQ88Engine : Engine {
     int bestW = 0, bestG = 0;
     double best = -1;
     use_reg = false;
+    layered = o.layer_checks > 0;
+    if (layered) {
+      // layered schedule: one layer = one round of the generic kernel, so the workgroup has
+      // layer_checks threads (ldpc_hip.h, ldpc_opts.layer_checks)
+      const int L = o.layer_checks;
+      if (L % 64 || L < 64 || L > 1024 || (m + L - 1) / L > 8) {
+        ldpc_set_error("layer_checks must be a multiple of 64 with m/8 <= layer_checks <= 1024");
+        return LDPC_ERR_UNSUPPORTED;
+      }
+      env_reg = 0;
+      env_w = L / 64;
+      env_g = std::max(1, std::min(wg_per_cu, 1024 / L));
+    }
     if (env_reg && rmax <= 64) {
       for (int G = 1; G <= wg_per_cu; G++)
         for (int W = 1; W * G <= 16; W++) {
@@ -810,7 +823,7 @@ struct FusedQ88Engine : Engine {
     if ((rc = d_counter.ensure(256))) return rc;
     if (getenv("LDPC_HIP_VERBOSE"))
       fprintf(stderr, "ldpc_hip: fused Q8.8 decoder: %d threads x %d workgroup(s) per CU, %d check(s) per thread, %s, %zu B LDS\n",
-              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : "generic kernel", lds);
+              block, wg_per_cu, rounds, use_reg ? "register-cached kernel" : layered ? "generic kernel, layered schedule" : "generic kernel", lds);
     return LDPC_OK;
   }
 
@@ -836,6 +849,7 @@ struct FusedQ88Engine : Engine {
     a.maskT = d_maskT.as<uint32_t>();
     a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
     a.timing = nullptr;
+    a.layered = layered ? 1 : 0;
     const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;   // (only timing builds of the kernel write it)
     if (timing) {
       if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
@@ -946,6 +960,10 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
   if (d->opts.max_frames <= 0) d->opts.max_frames = 4096;
   d->max_frames = d->opts.max_frames;
   const bool binary = c->q == 2;
+  if (opts->layer_checks != 0 && (opts->alg != LDPC_ALG_MINSUM_Q88 || !binary || opts->layer_checks < 0)) {
+    ldpc_set_error("layer_checks (layered schedule) is available for MINSUM_Q88 on binary codes only");
+    return LDPC_ERR_UNSUPPORTED;
+  }
   const char *fe = getenv("LDPC_HIP_FUSED");
   const int fmode = fe ? atoi(fe) : 1;
   switch (opts->alg) {
@@ -971,6 +989,15 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
         // LDPC_HIP_FUSED=0) selects the two-pass HBM engine
         // (LDPC_HIP_FUSED=2 also allows the generic fused kernel where no register-cached one exists)
         bool fused = opts->cn_variant == 0 && FusedQ88Engine::fits(*c);
+        if (opts->layer_checks > 0) {
+          // the layered schedule lives in the frame-resident decoder only
+          if (!FusedQ88Engine::fits(*c)) {
+            ldpc_set_error("layer_checks: the layered schedule needs a frame that fits LDS (n <= ~40000, row weight <= 64)");
+            return LDPC_ERR_UNSUPPORTED;
+          }
+          d->eng.reset(new FusedQ88Engine);
+          break;
+        }
         fused = fused && fmode != 0 && (fmode == 2 || FusedQ88Engine::reg_kernel_available(*c));
         if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which

@@ -32,7 +32,7 @@ _NP2DT = {np.dtype(np.float64): DT.F64, np.dtype(np.float32): DT.F32,
 class _Opts(C.Structure):
     _fields_ = [("alg", C.c_int32), ("device", C.c_int32), ("max_frames", C.c_int32),
                 ("early_exit", C.c_int32), ("want_llr", C.c_int32), ("cn_variant", C.c_int32),
-                ("reserved", C.c_int32 * 10)]
+                ("layer_checks", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class _McOpts(C.Structure):
@@ -219,13 +219,14 @@ class Decoder:
     """One GPU decoder for one code and one algorithm (replaces dec())."""
 
     def __init__(self, code, alg, device=0, max_frames=4096, early_exit=True, want_llr=False,
-                 cn_variant=0):
+                 cn_variant=0, layer_checks=0):
         L = load_library()
         self.code = code
         self.alg = alg
         o = _Opts()
         o.alg, o.device, o.max_frames = alg, device, max_frames
         o.early_exit, o.want_llr, o.cn_variant = int(early_exit), int(want_llr), cn_variant
+        o.layer_checks = int(layer_checks)   # 0: flooding (the reference's schedule); L: layers of L checks
         h = C.c_void_p()
         check(L.ldpc_decoder_create(code._h, C.byref(o), C.byref(h)))
         self._h = h

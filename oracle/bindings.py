@@ -77,6 +77,7 @@ class Oracle:
         L.ora_dec_minsum_f32.argtypes = [cp, _f32p, _i32p, C.c_int, _i32p, _i32p, ip, C.c_void_p]
         L.ora_dec_minsum_fixed.argtypes = [cp, _f64p, _i32p, C.c_int, _i32p, _i32p, ip,
                                            C.c_void_p, C.c_void_p, C.c_int]
+        L.ora_dec_minsum_fixed_layered.argtypes = [cp, _f64p, _i32p, C.c_int, C.c_int, _i32p, _i32p, ip, C.c_void_p]
         L.ora_dec_spa.argtypes = [cp, _f64p, _i32p, C.c_int, _i32p, _i32p, ip, C.c_void_p]
         L.ora_dec_spa_f32.argtypes = [cp, _f32p, _i32p, C.c_int, _i32p, _i32p, ip, C.c_void_p]
         L.ora_dec_spa_table.argtypes = [cp, _i32p, _i32p, C.c_int, _i32p, _i32p, ip, C.c_void_p]
@@ -138,6 +139,18 @@ class Oracle:
         finally:
             if fp:
                 self._libc.fclose(fp)
+
+    def dec_minsum_fixed_layered(self, code, q0, s, loop_max, layer):
+        """Q8.8 min-sum on a layered schedule (layers of `layer` consecutive checks)."""
+        q0 = np.ascontiguousarray(q0, np.float64)
+        s = np.zeros(code.m, np.int32) if s is None else np.ascontiguousarray(s, np.int32)
+        bits = np.zeros(code.n, np.int32)
+        synd = np.zeros(code.m, np.int32)
+        it = C.c_int(0)
+        post = np.zeros(code.n, np.float64)
+        rc = self.lib.ora_dec_minsum_fixed_layered(code._p, q0, s, int(loop_max), int(layer), bits, synd,
+                                                   C.byref(it), post.ctypes.data_as(C.c_void_p))
+        return dict(rc=rc, bits=bits, synd=synd, iters=it.value, post=post)
 
     def dec_spa(self, code, q0, s, loop_max):
         return self._run(self.lib.ora_dec_spa, code, q0, s, loop_max, np.float64, np.float64)

@@ -244,6 +244,71 @@ int ora_dec_minsum_fixed(const ora_code *c, const double *q0, const int *s, int 
   return dec_minsum_any(c, q0, s, loop_max, bits, synd, iters, post, 1, trace, circ_size);
 }
 
+/* Layered (row-block serial) schedule of the Q8.8 min-sum decoder.  NOT in the reference (SURVEY 8 f4
+ * "alternative schedules"): the arithmetic of every message is dec()'s (test_code_min_sum_B_fixed.c:
+ * 213-229 v2c = float_to_fix(|sum - c2v|) with its sign, :264-283 min / sign product with the 200 cap),
+ * the pre-check (:198-207) and the per-iteration exit test (:298-313) are dec()'s; only the ORDER of
+ * the updates differs: an iteration walks the checks in layers of `layer` consecutive rows; the checks
+ * of one layer all read the sums as the previous layer left them, then their new messages replace
+ * their old ones in the sums (sum += new - old) before the next layer reads.  layer >= m is the
+ * reference's flooding schedule, and then this function returns exactly what ora_dec_minsum_fixed
+ * does (tests/test_oracle_golden.py pins it that way). */
+int ora_dec_minsum_fixed_layered(const ora_code *c, const double *q0, const int *s, int loop_max,
+                                 int layer, int *bits, int *synd, int *iters, double *post)
+{
+  int i, j, k, l, loop, n = c->n, m = c->m, rc = 1;
+  double *sum = (double *)calloc((size_t)n + 1, sizeof(double));
+  double *c2v = (double *)calloc((size_t)m * c->rmax + 1, sizeof(double));   /* all 0, _fixed.c:196 */
+  double *nw = (double *)calloc((size_t)m * c->rmax + 1, sizeof(double));
+  *iters = 0;
+  if (layer < 1) layer = m;
+  for (i = 0; i < n; i++) { sum[i] = q0[i]; if (post) post[i] = q0[i]; }
+  for (i = 0; i < n; i++) bits[i] = (q0[i] < 0) ? 1 : 0;
+  ora_enc(c, bits, synd);
+  if (hamdist(s, synd, m) == 0) { rc = 0; goto out; }
+
+  for (loop = 0; loop < loop_max; loop++) {
+    int j0;
+    for (j0 = 0; j0 < m; j0 += layer) {
+      int j1 = j0 + layer < m ? j0 + layer : m;
+      for (j = j0; j < j1; j++) {                 /* every check of the layer reads the same sums */
+        int w = c->row_weight[j], sgnprod = s[j];
+        double mag[256];
+        int sg[256];
+        for (k = 0; k < w; k++) {
+          double qout = sum[c->row_col[j * c->rmax + k]] - c2v[(size_t)j * c->rmax + k];
+          sg[k] = qout < 0;
+          mag[k] = ora_float_to_fix(qout < 0 ? -qout : qout);
+          sgnprod ^= sg[k];
+        }
+        for (k = 0; k < w; k++) {
+          double min_msg = 200;
+          for (l = 0; l < w; l++)
+            if (l != k && mag[l] < min_msg) min_msg = mag[l];
+          nw[(size_t)j * c->rmax + k] = (sgnprod != sg[k]) ? -min_msg : min_msg;
+        }
+      }
+      for (j = j0; j < j1; j++)                   /* then their messages are exchanged in the sums */
+        for (k = 0; k < c->row_weight[j]; k++) {
+          size_t e = (size_t)j * c->rmax + k;
+          sum[c->row_col[j * c->rmax + k]] += nw[e] - c2v[e];
+          c2v[e] = nw[e];
+        }
+    }
+    for (i = 0; i < n; i++) {
+      double sat = ora_float_to_fix(sum[i]);      /* _fixed.c:303 */
+      if (post) post[i] = sat;
+      bits[i] = (sat < 0) ? 1 : 0;
+    }
+    ora_enc(c, bits, synd);
+    *iters = loop + 1;
+    if (hamdist(s, synd, m) == 0) { rc = 0; goto out; }
+  }
+out:
+  free(sum); free(c2v); free(nw);
+  return rc;
+}
+
 /* binary32 twin of ora_dec_minsum (same statements, float arithmetic). */
 int ora_dec_minsum_f32(const ora_code *c, const float *q0, const int *s, int loop_max,
                        int *bits, int *synd, int *iters, float *post)

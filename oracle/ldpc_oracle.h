@@ -69,6 +69,12 @@ int ora_dec_minsum_fixed(const ora_code *c, const double *q0, const int *s,
                          int loop_max, int *bits, int *synd, int *iters,
                          double *post, FILE *trace, int circ_size);
 
+/* The same arithmetic on a layered schedule (layers of `layer` consecutive checks; not in the
+ * reference -- see the function's header in ldpc_oracle.c).  layer >= m: flooding, identical
+ * to ora_dec_minsum_fixed.                                                    */
+int ora_dec_minsum_fixed_layered(const ora_code *c, const double *q0, const int *s, int loop_max,
+                                 int layer, int *bits, int *synd, int *iters, double *post);
+
 /* dec(), double sum-product (test_code_B_float.c:134-199). */
 int ora_dec_spa(const ora_code *c, const double *q0, const int *s,
                 int loop_max, int *bits, int *synd, int *iters, double *post);
