@@ -772,6 +772,13 @@ struct FusedQ88Engine : Engine {
         ldpc_set_error("LDS schedule: code too large");
         return LDPC_ERR_UNSUPPORTED;
       }
+      // A dummy word starts 2^24 above the bias and has to stay a pad ("huge, positive") through a
+      // phase B in which every pad slot pointing at it adds up to +-200.0 (FQ_CAP): at most 10^7 / FQ_CAP
+      // pad slots per word.  Very irregular codes (many pads) go to the two-pass engine instead.
+      if ((long)sched.max_dummy_load * FQ_CAP > 10000000L) {
+        ldpc_set_error("fused Q8.8 decoder: too many padded slots per dummy word for this code's row weights");
+        return LDPC_ERR_UNSUPPORTED;
+      }
       lds = (size_t)(sched.words + 4) * 4;
       // SH = 0 packs absolute 16-bit LDS byte addresses: the dynamic array starts after the
       // kernel's static LDS (the scratch of __syncthreads_or), so that must fit as well
@@ -1021,6 +1028,13 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
     return LDPC_ERR_UNSUPPORTED;
   }
   int rc = d->eng->init(d->code, d->opts);
+  if (rc == LDPC_ERR_UNSUPPORTED && opts->alg == LDPC_ALG_MINSUM_Q88 && opts->layer_checks == 0 &&
+      dynamic_cast<FusedQ88Engine *>(d->eng.get())) {
+    // a shape the frame-resident decoder turns down after all (schedule limits): two-pass engine
+    if (c->min_row_weight >= 2) d->eng.reset(new BinaryEngine<short, ALG_MSQ>);
+    else d->eng.reset(new BinaryEngine<int, ALG_MSQ>);
+    rc = d->eng->init(d->code, d->opts);
+  }
   if (rc) return rc;
   *out = d.release();
   return LDPC_OK;

@@ -226,6 +226,15 @@ int ldpc_build_lds_schedule(const ldpc_code &c, int block, int RM, int ndummy, b
       out.dcT[(size_t)(j / block) * block + j % block] = (uint8_t)std::min(255, c.row_ptr[j + 1] - c.row_ptr[j]);
     }
   }
+  {
+    // pad slots per dummy word: each adds a bounded amount to it in phase B, so the kernels can
+    // only promise "huge and positive" dummies up to a load (FusedQ88Engine checks it)
+    std::vector<int> load((size_t)ndummy, 0);
+    for (uint16_t w : out.colT)
+      if (w >= out.dummy_base) load[w - out.dummy_base]++;
+    out.max_dummy_load = 0;
+    for (int x : load) out.max_dummy_load = std::max(out.max_dummy_load, x);
+  }
   if (optimise && out.conflicts > 0) {
     // structured (e.g. quasi-cyclic) codes can be conflict free just as they stand, and a slot
     // count with no slack leaves the colouring no room: keep whichever placement is better

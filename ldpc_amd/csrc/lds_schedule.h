@@ -13,6 +13,7 @@ struct LdsSchedule {
   std::vector<uint32_t> maskT;   // [rounds][block][nw]  sign-mask bits of the real slots
   std::vector<uint8_t> dcT;      // [rounds][block]      row weight (0: no such check)
   long conflicts = 0, accesses = 0;   // extra LDS cycles / half-wave accesses per iteration pass
+  int max_dummy_load = 0;             // most pad slots of the workgroup that point at one dummy word
 };
 
 // block: threads per workgroup (multiple of 64); RM: slots per check (even, >= rmax);

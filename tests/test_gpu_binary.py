@@ -242,6 +242,49 @@ def test_fused_q88_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it):
     check_exact(dflt.decode(raw, s.astype(np.uint8), it), ref, f"random {n}x{m} dv={dv} default engine")
 
 
+@pytest.mark.parametrize("shape", ["ragged_rows", "heavy_column"])
+def test_q88_on_shapes_the_fused_decoder_must_turn_down(hip, oracle, tmp_path, shape):
+    """Two limits of the register-cached Q8.8 kernel, both checked on the host when the decoder is made
+    (the decoder then falls back to the two-pass engine and the results must still be the oracle's):
+    ragged_rows  -- 992 rows of weight 2 next to 8 rows of weight 58 (one check per thread, a shape
+                    the kernel is built for): every check is padded to 60 slots, ~230 pad slots share
+                    each dummy LDS word, more than a dummy can absorb in one phase B and stay a pad;
+    heavy_column -- one variable in 48 checks: its sum can exceed the exact range of the biased LDS
+                    words (column weight <= 39)."""
+    rng = np.random.default_rng(77)
+    if shape == "ragged_rows":
+        n, m = 1100, 1000
+        H = np.zeros((m, n), np.uint8)
+        for j in range(992):                                # a chain: row j checks variables j, j+1
+            H[j, j] = 1
+            H[j, j + 1] = 1
+        for j in range(992, m):
+            H[j, rng.choice(n, 58, replace=False)] = 1
+        p = 0.004
+    else:
+        n, m = 1500, 300
+        H = _random_code(rng, n, m, 3)
+        H[:, 7] = 0
+        H[rng.choice(m, 48, replace=False), 7] = 1
+        p = 0.02
+    path = str(tmp_path / "odd.alist")
+    hip.alist.matrix_to_alist(H, path)
+    oc = oracle.load(path)
+    code = hip.Code.from_alist(path)
+    x, s, llr = make_frames(oracle, oc, 24, p, 9, "bsc")
+    q, raw = to_q88(llr)
+    it = 12
+    ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q, s, it)
+    import os
+    for fused in ("1", "2"):                                # default choice; generic fused kernel allowed
+        os.environ["LDPC_HIP_FUSED"] = fused
+        try:
+            dec = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=64, early_exit=True)
+        finally:
+            del os.environ["LDPC_HIP_FUSED"]
+        check_exact(dec.decode(raw, s.astype(np.uint8), it), ref, f"{shape} LDPC_HIP_FUSED={fused}")
+
+
 @pytest.mark.parametrize("n,m,dv,it", [(96, 48, 3, 10), (520, 130, 3, 12), (2000, 200, 3, 8), (3000, 150, 3, 8),
                                        (1200, 1150, 3, 15), (4000, 1000, 4, 8), (777, 259, 5, 10), (6000, 300, 2, 6),
                                        (2044, 1022, 6, 10), (6000, 4000, 3, 10)])
