@@ -416,7 +416,14 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
   const int tid = threadIdx.x, B = blockDim.x;
   int *frame_slot = (int *)(fsum + a.words);
   constexpr int RM = 2 * R2;
-  constexpr int CH = RM < 8 ? RM : 8;          // LDS reads in flight per check
+#ifndef LDPC_FUSED_CH
+#define LDPC_FUSED_CH 0   /* 0: four reads per check in flight with two or more checks per thread, else eight (measured) */
+#endif
+#ifndef LDPC_FUSED_BCH
+#define LDPC_FUSED_BCH 8
+#endif
+  constexpr int CHMAX = LDPC_FUSED_CH ? LDPC_FUSED_CH : (CPT >= 2 ? 4 : 8);
+  constexpr int CH = RM < CHMAX ? RM : CHMAX;  // LDS reads in flight per check
   constexpr int NW = (RM + 31) / 32;           // sign-mask words per check
   constexpr int WB = RM < 32 ? RM : 32;        // slots per mask word
   constexpr int KB = RM <= 32 ? 5 : 6;         // key bits that hold the slot
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             if (LDPC_FUSED_ABLATE & 1) asm volatile("" ::"v"(delta), "v"(dst));
             else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
+            if ((k & (LDPC_FUSED_BCH - 1)) == LDPC_FUSED_BCH - 1) __builtin_amdgcn_sched_barrier(0);   // bounds the live registers
           }
           {
             // slot oarg really carried +-min2 before; slot narg carries +-min2 now
