@@ -534,8 +534,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       // Phase A for the first NA of the thread's checks.  NA is CPT except in wavefronts whose
       // last round holds no check at all (the rounds fill up in order, so those have exactly
       // CPT - 1): they run the shorter instruction stream instead of walking dummy slots.
-      auto phase_a = [&](auto na_c) {
+      // FIRST: the first iteration of a frame, where every old message is +0 -- no min1/min2 select, no
+      // sign to inject (phase A: 2 of 9.5 instructions per slot less; phase B: 3 of 7)
+      auto phase_a = [&](auto na_c, auto first_c) {
         constexpr int NA = decltype(na_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
         // keep the offsets packed: the empty asm makes the unpacking loop-variant for the
         // compiler, which would otherwise hoist 2*R2 unpacked addresses per check
         unsigned k1[CPT], k2m[CPT], pp[CPT], sg[CPT][NW];
@@ -544,10 +547,12 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
         // AND of those on the scalar unit, which has nothing else to do, instead of a vector
         // compare per slot.
         unsigned long long ab[CPT][KB];
+        if constexpr (!FIRST) {
 #pragma unroll
-        for (int r = 0; r < NA; r++)
+          for (int r = 0; r < NA; r++)
 #pragma unroll
-          for (int b = 0; b < KB; b++) ab[r][b] = __ballot((oarg[r] >> b) & 1u);
+            for (int b = 0; b < KB; b++) ab[r][b] = __ballot((oarg[r] >> b) & 1u);
+        }
 #pragma unroll
         for (int r = 0; r < NA; r++) {
           k1[r] = k2m[r] = 0xffffffffu;
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           // One register per mask word serves both directions: the old signs leave at the top
           // (the slot in turn is always bit 31) while the new ones enter at the bottom, one
           // v_alignbit per slot; after the word's last slot only new signs are left.
-          for (int w = 0; w < NW; w++) sg[r][w] = osg[r][w] << (32 - WB);
+          for (int w = 0; w < NW; w++) sg[r][w] = FIRST ? 0u : osg[r][w] << (32 - WB);
         }
         // the thread's checks advance together, CH slots at a time: CPT*CH independent LDS
         // reads in flight and CPT independent min chains
@@ -586,15 +591,18 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
                 // hard-decision parity, two slots per v_bitop3 (x ^ y ^ z); CH and RM are even
                 pp[r] = __builtin_amdgcn_bitop3_b32(pp[r], (unsigned)S[r][j], (unsigned)S[r][j + 1], 0x96);
               }
-              float mo;
-              if (LDPC_FUSED_ABLATE & 64) mo = om1[r];
-              else {
-                unsigned long long in_k = (k & 1) ? ab[r][0] : ~ab[r][0];
+              float q = __uint_as_float((unsigned)S[r][j]);     // (FIRST: sum - (+0))
+              if constexpr (!FIRST) {
+                float mo;
+                if (LDPC_FUSED_ABLATE & 64) mo = om1[r];
+                else {
+                  unsigned long long in_k = (k & 1) ? ab[r][0] : ~ab[r][0];
 #pragma unroll
-                for (int b = 1; b < KB; b++) in_k &= ((k >> b) & 1) ? ab[r][b] : ~ab[r][b];
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
+                  for (int b = 1; b < KB; b++) in_k &= ((k >> b) & 1) ? ab[r][b] : ~ab[r][b];
+                  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(mo) : "v"(om1[r]), "v"(om2[r]), "s"(in_k));
+                }
+                q = q - __uint_as_float(FQ_ANDOR(sg[r][k / 32], 0x80000000u, __float_as_uint(mo)));
               }
-              const float q = __uint_as_float((unsigned)S[r][j]) - __uint_as_float(FQ_ANDOR(sg[r][k / 32], 0x80000000u, __float_as_uint(mo)));
               sg[r][k / 32] = __builtin_amdgcn_alignbit(sg[r][k / 32], __float_as_uint(q), 31);
               const unsigned key = (LDPC_FUSED_ABLATE & 256) ? __float_as_uint(q) : FQ_ANDOR(__float_as_uint(q), 0x7fffffffu, (unsigned)k);
               if (LDPC_FUSED_ABLATE & 16) k2m[r] ^= key & k1[r];
@@ -663,8 +671,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       if (t == a.max_iter + 1) {
         if (wave_full) parity_only(std::integral_constant<int, CPT>{});
         else parity_only(std::integral_constant<int, CPT - 1>{});
-      } else if (wave_full) phase_a(std::integral_constant<int, CPT>{});
-      else phase_a(std::integral_constant<int, CPT - 1>{});
+      } else if (t == 1) {
+        if (wave_full) phase_a(std::integral_constant<int, CPT>{}, std::true_type{});
+        else phase_a(std::integral_constant<int, CPT - 1>{}, std::true_type{});
+      } else if (wave_full) phase_a(std::integral_constant<int, CPT>{}, std::false_type{});
+      else phase_a(std::integral_constant<int, CPT - 1>{}, std::false_type{});
       FQ_TICK(tc1);
       const int any_bad = (LDPC_FUSED_ABLATE & 4) ? 1 : fq_block_or(bad, frame_slot + 1, t);
       FQ_TICK(tc2);
@@ -677,8 +688,9 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
       // slot of min1 itself, where it is +-min2.  The slot loop treats every slot as
       // "+-min1" (integer arithmetic on sign masks, no per-slot selects) and the two
       // exceptional slots are put right afterwards by one extra add each.
-      auto phase_b = [&](auto na_c) {
+      auto phase_b = [&](auto na_c, auto first_c) {
         constexpr int NA = decltype(na_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
 #pragma unroll
         for (int r = 0; r < NA; r++) {
           // (re)derive everything from the compressed state here, not before the barrier
@@ -693,10 +705,14 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           for (int k = 0; k < RM; k++) {
             lds_int *dst = (k & 1) ? fq_slot_ptr<1, SH>(lbase, idx[r][k >> 1]) : fq_slot_ptr<0, SH>(lbase, idx[r][k >> 1]);
             const float cn = __uint_as_float(FQ_ANDOR(nrot[k / 32], 0x80000000u, __float_as_uint(nm1[r])));
-            const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
             nrot[k / 32] = fq_shl1(nrot[k / 32]);
-            prot[k / 32] = fq_shl1(prot[k / 32]);
-            const int delta = (LDPC_FUSED_ABLATE & 128) ? (int)__float_as_uint(cn - co) : (int)(cn - co);
+            float d = cn;                        // (FIRST: the old message is +0)
+            if constexpr (!FIRST) {
+              const float co = __uint_as_float(FQ_ANDOR(prot[k / 32], 0x80000000u, __float_as_uint(om1[r])));
+              prot[k / 32] = fq_shl1(prot[k / 32]);
+              d = cn - co;
+            }
+            const int delta = (LDPC_FUSED_ABLATE & 128) ? (int)__float_as_uint(d) : (int)d;
             if (LDPC_FUSED_ABLATE & 1) asm volatile("" ::"v"(delta), "v"(dst));
             else
             __hip_atomic_fetch_add(dst, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
             const unsigned ao = oarg[r], an = narg[r];   // < RM: a real slot always wins the minimum
             const int so = -(int)((osg[r][ao / 32] >> (WB - 1 - (ao % 32))) & 1u);
             const int sn = -(int)((nsg[r][an / 32] >> (WB - 1 - (an % 32))) & 1u);
-            atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));
+            if constexpr (!FIRST) atomicAdd((int *)(lds + ooff[r]), -((dmo ^ so) - so));   // (FIRST: min2 - min1 = 0)
             atomicAdd((int *)(lds + noff[r]), (dmn ^ sn) - sn);
           }
           om1[r] = nm1[r]; om2[r] = nm2[r]; oarg[r] = narg[r]; ooff[r] = noff[r];
@@ -716,8 +732,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
           for (int w = 0; w < NW; w++) osg[r][w] = nsg[r][w];
         }
       };
-      if (wave_full) phase_b(std::integral_constant<int, CPT>{});
-      else phase_b(std::integral_constant<int, CPT - 1>{});
+      if (t == 1) {
+        if (wave_full) phase_b(std::integral_constant<int, CPT>{}, std::true_type{});
+        else phase_b(std::integral_constant<int, CPT - 1>{}, std::true_type{});
+      } else if (wave_full) phase_b(std::integral_constant<int, CPT>{}, std::false_type{});
+      else phase_b(std::integral_constant<int, CPT - 1>{}, std::false_type{});
       FQ_TICK(tc3);
       if (!(LDPC_FUSED_ABLATE & 4)) __syncthreads();
       FQ_TICK(tc4);
