@@ -71,6 +71,36 @@ struct FfArgs {
 
 template <int NW> struct FfSgw { static constexpr int value = NW == 1 ? 2 : 4; };
 
+// Pieces of the generic kernel's check pass, written once for binary32 and binary64: the word that
+// holds the sign, a select on a 64-lane mask held in scalar registers, and min / max against |x|
+// as single instructions (the C library forms come with NaN-quieting instructions around them;
+// every operand here is finite).
+__device__ __forceinline__ uint32_t ff_hi(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ uint32_t ff_hi(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ float ff_xor_hi(float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) ^ m); }
+__device__ __forceinline__ double ff_xor_hi(double x, uint32_t m) {
+  return __hiloint2double((int)((uint32_t)__double2hiint(x) ^ m), __double2loint(x));
+}
+__device__ __forceinline__ float ff_pick(float a, float b, unsigned long long take_b) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(take_b));
+  return r;
+}
+__device__ __forceinline__ double ff_pick(double a, double b, unsigned long long take_b) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(a)), "v"(__double2loint(b)), "s"(take_b));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(a)), "v"(__double2hiint(b)), "s"(take_b));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool ff_abs_lt(float x, float m) { return __builtin_fabsf(x) < m; }
+__device__ __forceinline__ bool ff_abs_lt(double x, double m) { return __builtin_fabs(x) < m; }
+__device__ __forceinline__ float ff_min_abs(float a, float x) { float r; asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x)); return r; }
+__device__ __forceinline__ float ff_max_abs(float a, float x) { float r; asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x)); return r; }
+__device__ __forceinline__ float ff_min2(float a, float b) { float r; asm("v_min_f32_e64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double ff_min_abs(double a, double x) { double r; asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x)); return r; }
+__device__ __forceinline__ double ff_max_abs(double a, double x) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x)); return r; }
+__device__ __forceinline__ double ff_min2(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // QG: the frame's channel LLRs stay in global memory (a.q0g, placed order, written once per frame
 // and re-read by every variable pass) instead of LDS, and the check records are packed
 // (sign words, then one byte per check for the slot of min1): binary64 sums of a 16 000-variable
@@ -152,6 +182,10 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
           uint32_t arg = 0, p = 0, sg[NW];
 #pragma unroll
           for (int w = 0; w < NW; w++) sg[w] = 0;
+          // the low bits of the previous minimum's slot, transposed into lane masks (see the chunk loop)
+          unsigned long long ob[3];
+#pragma unroll
+          for (int b = 0; b < 3; b++) ob[b] = __ballot((oarg[r] >> b) & 1u);
           // eight slots at a time (then the rest in pairs: RM is even): their indices (global, L2)
           // and then their sums (LDS) are all requested before the first is used -- one index
           // load per slot in a dependent chain was most of this kernel's time.
@@ -163,23 +197,42 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
             for (int jj = 0; jj < CK; jj++) wv[jj] = (int)col[(size_t)(k0 + jj) * B];
 #pragma unroll
             for (int jj = 0; jj < CK; jj++) Sv[jj] = sumL[wv[jj]];
+            // Branch-free, and with the per-slot questions answered once per chunk where they can be:
+            // k0 is uniform and a multiple of CK, so "is the previous minimum in this chunk" is one
+            // compare per chunk (the slot inside it: scalar ANDs of lane masks), the old signs of the
+            // chunk are one shift, the new ones are collected in a register of their own and merged
+            // into the mask word once.
+            constexpr int LBITS = CK == 8 ? 3 : 1;
+            const int w = NW == 1 ? 0 : (k0 >> 5);
+            uint32_t osw = osg[r][0];
+            if (NW > 1 && w) osw = osg[r][NW - 1];
+            const uint32_t orot = osw >> (k0 & 31);                 // bit jj: old sign of slot k0 + jj
+            const unsigned long long own = __ballot((oarg[r] >> LBITS) == (uint32_t)(k0 >> LBITS));
+            uint32_t acc = 0;
 #pragma unroll
             for (int jj = 0; jj < CK; jj++) {
-              const int k = k0 + jj;
               const T S = Sv[jj];
-              p ^= (uint32_t)(S < (T)0);
-              T co = ((uint32_t)k == oarg[r]) ? om2[r] : om1[r];
-              if ((osg[r][NW == 1 ? 0 : (k >> 5)] >> (k & 31)) & 1u) co = -co;
+              p ^= ff_hi(S);                                        // (bit 31: S < 0; sums are stored as S + 0)
+              unsigned long long in_k = own;
+#pragma unroll
+              for (int b = 0; b < LBITS; b++) in_k &= ((jj >> b) & 1) ? ob[b] : ~ob[b];
+              const T mo = ff_pick(om1[r], om2[r], in_k);           // min2 in the slot of min1
+              const T co = ff_xor_hi(mo, (orot << (31 - jj)) & 0x80000000u);
               const T q = S - co;                                   // :150
-              const T mag = q < (T)0 ? -q : q;
-              if (q < (T)0) sg[NW == 1 ? 0 : (k >> 5)] |= 1u << (k & 31);
-              if (mag < m1) { m2 = m1; m1 = mag; arg = (uint32_t)k; }
-              else if (mag < m2) { m2 = mag; }
+              acc = (acc >> 1) | (ff_hi(q) & 0x80000000u);
+              const bool lt = ff_abs_lt(q, m1);
+              m2 = ff_min2(m2, ff_max_abs(m1, q));
+              arg = lt ? (uint32_t)(k0 + jj) : arg;
+              m1 = ff_min_abs(m1, q);
             }
+            const uint32_t fresh = (acc >> (32 - CK)) << (k0 & 31);  // new signs of the chunk, at their slots
+            if (NW == 1 || !w) sg[0] |= fresh;
+            else sg[NW - 1] |= fresh;
           };
           int k0 = 0;
           for (; k0 + 8 <= a.RM; k0 += 8) slots(k0, std::integral_constant<int, 8>{});
           for (; k0 < a.RM; k0 += 2) slots(k0, std::integral_constant<int, 2>{});
+          p >>= 31;
           par[r] = (int)p;
           bad |= (int)p ^ sbit[r];
           // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:177-178)
@@ -221,12 +274,14 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
           for (int c = 0; c < KC; c++)
 #pragma unroll
             for (int u = 0; u < VU; u++) {
+              // (one magnitude is read, after the slot of min1 is known: reading both and choosing in
+              // registers doubles the LDS traffic of this pass and measured 12.9 against 17.8 Gbit/s)
               const uint32_t e = ev[u][c];
               const int j = (int)(e >> 8), p = (int)(e & 0xffu);
               const uint32_t sw = sgL[SGW * j + (NW == 1 ? 0 : (p >> 5))];
               const uint32_t arg = QG ? (uint32_t)argL[j] : sgL[SGW * j + NW];
               const T mg = magL[2 * j + (arg == (uint32_t)p ? 1 : 0)];
-              sum[u] = sum[u] + (((sw >> (p & 31)) & 1u) ? -mg : mg);
+              sum[u] = sum[u] + ff_xor_hi(mg, (sw << (31 - (p & 31))) & 0x80000000u);
             }
         };
         int kk0 = 0;
