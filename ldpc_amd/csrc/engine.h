@@ -167,3 +167,6 @@ Engine *ldpc_make_gf_engine(int alg, const ldpc_code &c);
 // fused_float.hip: frame-resident floating-point min-sum (prec 4: binary32, 8: binary64);
 // nullptr when the code does not fit in LDS
 Engine *ldpc_make_fused_float_engine(int prec, const ldpc_code &c);
+// chain_q88.hip: frame-resident Q8.8 min-sum for staircase (IRA / DVB-S2) codes too large for the
+// fused decoder's LDS sums; init() returns LDPC_ERR_UNSUPPORTED for codes it does not serve
+Engine *ldpc_make_chain_q88_engine();

@@ -1006,6 +1006,19 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
           break;
         }
         fused = fused && fmode != 0 && (fmode == 2 || FusedQ88Engine::reg_kernel_available(*c));
+        // codes whose frame is too large for that decoder but which have a staircase (DVB-S2 long
+        // frames): frame-resident with the staircase variables in registers (chain_q88.hip);
+        // LDPC_HIP_CHAIN=0 turns it off, =2 prefers it wherever it applies (tests on small codes)
+        const char *ce = getenv("LDPC_HIP_CHAIN");
+        const int cmode = ce ? atoi(ce) : 1;
+        if (opts->cn_variant == 0 && fmode != 0 && ((cmode == 1 && !fused) || cmode == 2)) {
+          std::unique_ptr<Engine> ch(ldpc_make_chain_q88_engine());
+          if (ch && ch->init(d->code, d->opts) == LDPC_OK) {
+            d->eng = std::move(ch);
+            *out = d.release();
+            return LDPC_OK;
+          }
+        }
         if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which
         // does not fit an int16 Q8.8 message: such codes use int32 messages

@@ -58,6 +58,6 @@ def make_frames(ora, ocode, F, p, seed, kind="bsc", zero_frac=0.5, sigma=None):
 
 def to_q88(llr):
     """float_to_fix() on an array -> values on the 1/256 grid (float64) and raw int16."""
-    r = np.round(np.abs(llr) * 256.0) * np.sign(llr)      # round half away from zero
+    r = np.floor(np.abs(llr) * 256.0 + 0.5) * np.sign(llr)  # C round(): half away from zero (np.round goes to even)
     r = np.clip(r, -128 * 256, 127 * 256)
     return r / 256.0, r.astype(np.int16)
