@@ -33,15 +33,16 @@
 
 #include "engine.h"
 #include "fused_kernels.hip.h"
+#include "lds_schedule.h"
 
 namespace ldpc {
 
 struct ChainArgs {
   const fq_u4 *tab;          // [R][block] one row per check: 6 LDS words (u16), spare, real-slot mask | flags << 8
-  const uint16_t *chainvar;  // [R + 1][block] staircase variable left of check 0, then right of check r (0xFFFF: none)
-  const uint16_t *pos;       // [n] variable -> LDS word (0xFFFF: staircase variable)
-  const uint32_t *wextra;    // [block / 64] bit r: some check r of the wavefront has slot 7
-  short *q0s;                // [grid][R + 1][block] channel values of the staircase variables
+  const uint16_t *chainvar;  // [R][block] staircase variable right of check r (0xFFFF: none)
+  const uint16_t *pos;       // [n] variable -> LDS word, or 0x8000 | j: the staircase variable right of check j
+  const uint32_t *wextra;    // [block / 64][3] per wavefront, bit r: some check r has slot 7 / lacks its right variable; bit 0: some check 0 lacks its left variable
+  short *q0s;                // [grid][R][block] channel values of the staircase variables (right of check r)
   uint32_t *nms;             // [grid][R][block] min1 | min2 << 16 of the current iteration, between the two phases
   int n, m, nframes, max_iter;
   const void *llr;
@@ -74,6 +75,17 @@ __device__ __forceinline__ unsigned long long cq_in_slot(const unsigned long lon
 __device__ __forceinline__ float cq_f(unsigned x) { return __uint_as_float(x); }
 __device__ __forceinline__ unsigned cq_u(float x) { return __float_as_uint(x); }
 
+// LDS byte address of one of the two 16-bit word indices packed in w: one SDWA shift
+template <int HI>
+__device__ __forceinline__ unsigned cq_addr(unsigned w) {
+  unsigned r;
+  if (HI) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(w));
+  return r;
+}
+// (the dynamic LDS array starts at LDS address 0: the kernel has no static LDS, which the host checks)
+__device__ __forceinline__ lds_int *cq_lds(unsigned byte_addr) { return (lds_int *)(unsigned long)byte_addr; }
+
 // BLK: workgroup size when it is known at compile time (row offsets become constants), else 0
 template <int R, int BLK>
 __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
@@ -82,10 +94,14 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
   int *frame_slot = fsum + a.words;            // [4]
   float *xR = (float *)(frame_slot + 4);       // [B + 2]  xR[i + 1]: message of thread i's last check to its right variable
   float *xL = xR + B + 2;                      // [B + 2]  xL[i]: message of thread i's first check to its left variable
-  const unsigned wex = __builtin_amdgcn_readfirstlane(a.wextra[tid >> 6]);
-  short *q0s = a.q0s + (size_t)blockIdx.x * (R + 1) * B + tid;
-  // (uniform bases for the loops below: an SGPR pair plus the thread's 32-bit offset per access)
-  const short *q0base = a.q0s + (size_t)blockIdx.x * (R + 1) * B;
+  unsigned *cbits = (unsigned *)(xL + B + 2);  // [B]      hard decisions of thread i's staircase variables (outputs)
+  // wave-uniform: bit r set if some check r of this wavefront has a slot 7 / lacks its right
+  // variable; bit 0 of the third word: some check 0 lacks its left variable
+  const unsigned wex = __builtin_amdgcn_readfirstlane(a.wextra[3 * (tid >> 6)]);
+  const unsigned wabs = __builtin_amdgcn_readfirstlane(a.wextra[3 * (tid >> 6) + 1]);
+  const unsigned wabsl = __builtin_amdgcn_readfirstlane(a.wextra[3 * (tid >> 6) + 2]);
+  // (uniform bases for the loops below)
+  short *q0base = a.q0s + (size_t)blockIdx.x * R * B;
   uint32_t *nmbase = a.nms + (size_t)blockIdx.x * R * B;
 
   // compressed messages: om = min1 | min2 << 16 of the previous iteration (the current one's waits
@@ -93,6 +109,10 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
   // enough to work with); as = signs | slot of min1 << 8, previous iteration in the low half,
   // current in the high half (signs: slot k in bit 7 - k)
   unsigned om[R], as[R];
+
+  const bool vec_in = a.dt == 2 && (a.n & 7) == 0 && ((size_t)a.llr & 15) == 0;
+  const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const fq_u4 *pos8 = (const fq_u4 *)a.pos;
 
   if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
   __syncthreads();
@@ -102,24 +122,43 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
     int next_frame = 0;
     if (tid == 0) next_frame = atomicAdd(a.counter, 1);
     const size_t base = (size_t)frame * a.n;
-    auto q0_of = [&](int i) -> int {             // float_to_fix for real-valued inputs, as bsc() :117-120
-      if (a.dt == 2) return ((const short *)a.llr)[base + i];
-      if (a.dt == 3) {
-        const int v = ((const int *)a.llr)[base + i];
-        return v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v);
+    {
+      // q0 of variable with table entry p: an LDS sum, or (bit 15) the right variable of check
+      // p & 0x7fff, parked in the row of the thread that owns that check
+      auto put = [&](const unsigned p, const int q) {
+        if (p & 0x8000u) {
+          const unsigned j = p & 0x7fffu;
+          q0base[(size_t)(j % R) * B + j / R] = (short)q;
+        } else fsum[p] = FQ_BIAS + q;
+      };
+      if (vec_in) {
+        const fq_u4 *p8 = (const fq_u4 *)((const short *)a.llr + base);
+        for (int i = tid; i < (a.n >> 3); i += B) {
+          const fq_u4 v = __builtin_nontemporal_load(p8 + i);
+          const fq_u4 w = pos8[i];
+          put(w.x & 0xffffu, (int)(short)(v.x & 0xffffu)); put(w.x >> 16, (int)v.x >> 16);
+          put(w.y & 0xffffu, (int)(short)(v.y & 0xffffu)); put(w.y >> 16, (int)v.y >> 16);
+          put(w.z & 0xffffu, (int)(short)(v.z & 0xffffu)); put(w.z >> 16, (int)v.z >> 16);
+          put(w.w & 0xffffu, (int)(short)(v.w & 0xffffu)); put(w.w >> 16, (int)v.w >> 16);
+        }
+      } else if (a.dt == 2) {
+        const short *p = (const short *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) put(a.pos[i], p[i]);
+      } else if (a.dt == 3) {
+        const int *p = (const int *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) {
+          const int v = p[i];
+          put(a.pos[i], v > FQ_SAT ? FQ_SAT : (v < -32768 ? -32768 : v));
+        }
+      } else if (a.dt == 1) {                      // float_to_fix for real-valued inputs, as bsc() :117-120
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) put(a.pos[i], fq_from_real((double)p[i]));
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) put(a.pos[i], fq_from_real(p[i]));
       }
-      if (a.dt == 1) return fq_from_real((double)((const float *)a.llr)[base + i]);
-      return fq_from_real(((const double *)a.llr)[base + i]);
-    };
-    for (int i = tid; i < a.n; i += B) {
-      const unsigned w = a.pos[i];
-      if (w != 0xffffu) fsum[w] = FQ_BIAS + q0_of(i);
     }
     for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;
-    for (int r = 0; r <= R; r++) {
-      const unsigned v = a.chainvar[(size_t)r * B + tid];
-      q0s[(size_t)r * B] = v != 0xffffu ? (short)q0_of((int)v) : (short)0;
-    }
     unsigned sbits = 0, parbits = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -142,6 +181,8 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       o.cl = cq_f(FQ_ANDOR(o.sgt, 0x80000000u, cq_u(cq_pick(o.m1, o.m2, cq_in_slot(o.ab, 0)))));
       o.cr = cq_f(FQ_ANDOR(o.sgt << 1, 0x80000000u, cq_u(cq_pick(o.m1, o.m2, cq_in_slot(o.ab, 1)))));
     };
+    // channel value of the variable left of the thread's first check: the previous thread's last row
+    auto left_q0 = [&](const CQ_GLOBAL short *q0u) { return (float)q0u[(size_t)(R - 1) * B + (tid ? tid - 1 : 0)]; };
 
     // Phase A: every check of the thread on the sums of the previous iteration.  PO: only the
     // parity of the hard decisions (the verdict after the last iteration).
@@ -153,33 +194,36 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       const short *q0_ = q0base;
       uint32_t *nm_ = nmbase;
       asm volatile("" : "+s"(tab_), "+s"(q0_), "+s"(nm_));
-      const CQ_GLOBAL fq_u4 *tabp = (const CQ_GLOBAL fq_u4 *)tab_ + tid;
-      const CQ_GLOBAL short *q0p = (const CQ_GLOBAL short *)q0_ + tid;
-      CQ_GLOBAL uint32_t *nmp = (CQ_GLOBAL uint32_t *)nm_ + tid;
+      const CQ_GLOBAL fq_u4 *tabu = (const CQ_GLOBAL fq_u4 *)tab_;
+      const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0_;
+      CQ_GLOBAL uint32_t *nmu = (CQ_GLOBAL uint32_t *)nm_;
       Open c, nx;
       open(om[0], as[0], c);
-      float Sl = 0.0f;
+      float Sl = left_q0(q0u) + xR[tid] + c.cl;
       unsigned pacc = 0;
+      fq_u4 w = (tabu)[tid];
+      if (wabsl && ((w.w >> 24) & 1u)) Sl = CQ_BIGF;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const fq_u4 w = tabp[(size_t)r * B];
         const bool ex = (wex >> r) & 1u;          // (wave-uniform)
         int Sw[6];
-        Sw[0] = fsum[w.x & 0xffffu]; Sw[1] = fsum[w.x >> 16];
-        Sw[2] = fsum[w.y & 0xffffu]; Sw[3] = fsum[w.y >> 16];
-        Sw[4] = fsum[w.z & 0xffffu];
+        Sw[0] = *cq_lds(cq_addr<0>(w.x)); Sw[1] = *cq_lds(cq_addr<1>(w.x));
+        Sw[2] = *cq_lds(cq_addr<0>(w.y)); Sw[3] = *cq_lds(cq_addr<1>(w.y));
+        Sw[4] = *cq_lds(cq_addr<0>(w.z));
         Sw[5] = 0;
-        if (ex) Sw[5] = fsum[w.z >> 16];
-        const float q0r = (float)q0p[(size_t)(r + 1) * B];
+        if (ex) Sw[5] = *cq_lds(cq_addr<1>(w.z));
+        const unsigned wflags = w.w;
+        // the next check's row while this one is worked on
+        if (r + 1 < R) w = (tabu + (size_t)(r + 1) * B)[tid];
+        const float q0r = (float)(q0u + (size_t)r * B)[tid];
         float cln;
         if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
         else cln = xL[tid + 1];
-        if (r == 0) {
-          Sl = (float)q0p[0] + xR[tid] + c.cl;
-          if ((w.w >> 24) & 1u) Sl = CQ_BIGF;
-        }
         float Sr = q0r + c.cr + cln;
-        if ((w.w >> 25) & 1u) Sr = CQ_BIGF;
+        if ((wabs >> r) & 1u) {                   // (rare: wave-uniform test first)
+          if ((wflags >> 26) & 1u) Sr = q0r + c.cr;          // private variable: no second check
+          if ((wflags >> 25) & 1u) Sr = CQ_BIGF;             // no variable
+        }
         float Sf[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) Sf[j] = cq_f((unsigned)Sw[j]) - FQ_BIASF;
@@ -208,19 +252,20 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
           const unsigned tot = (unsigned)__popc(sg) + (sbits >> r);
           const unsigned flip = (unsigned)(-(int)(tot & 1u));
-          const unsigned allm = (w.w >> 16) & 0xffu;
+          const unsigned allm = (wflags >> 16) & 0xffu;
           const unsigned nsg = __builtin_amdgcn_bitop3_b32(sg, allm, flip, 0x78);   // sg ^ (allm & flip)
           // min over saturated magnitudes = saturated min (:43-53, :269-277)
           // (non-negative floats order like their bit patterns: the clamp is an integer minimum)
           const float n1 = cq_f(min(k1 & ~7u, 0x46fe0000u /* 127.0 * 256 */));
           const float n2 = cq_f(min(k2 & ~7u, 0x46fe0000u));
-          nmp[(size_t)r * B] = (unsigned)n1 | ((unsigned)n2 << 16);
+          (nmu + (size_t)r * B)[tid] = (unsigned)n1 | ((unsigned)n2 << 16);
           as[r] = (as[r] & 0xffffu) | ((nsg | ((k1 & 7u) << 8)) << 16);
           // materialise the new state here: left alone the compiler sinks this arithmetic of all R
           // checks below the loop and keeps every check's signs and table row alive until then
           asm volatile("" : "+v"(as[r]));
         }
         Sl = Sr;
+        if (((wabs >> r) & 1u) && ((wflags >> 26) & 1u)) Sl = CQ_BIGF;   // (a private variable is not the next check's)
         if (r + 1 < R) c = nx;
         asm volatile("" : "+v"(pacc), "+v"(Sl));
         __builtin_amdgcn_sched_barrier(0);
@@ -240,21 +285,26 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       const fq_u4 *tab_ = a.tab;
       const uint32_t *nm_ = nmbase;
       asm volatile("" : "+s"(tab_), "+s"(nm_));
-      const CQ_GLOBAL fq_u4 *tabp = (const CQ_GLOBAL fq_u4 *)tab_ + tid;
-      const CQ_GLOBAL uint32_t *nmp = (const CQ_GLOBAL uint32_t *)nm_ + tid;
+      const CQ_GLOBAL fq_u4 *tabu = (const CQ_GLOBAL fq_u4 *)tab_;
+      const CQ_GLOBAL uint32_t *nmu = (const CQ_GLOBAL uint32_t *)nm_;
+      fq_u4 w = tabu[tid];
+      unsigned nmr = nmu[tid];
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const fq_u4 w = tabp[(size_t)r * B];
         const bool ex = (wex >> r) & 1u;
         const unsigned s = as[r];
         const float o1 = (float)(om[r] & 0xffffu), o2 = (float)(om[r] >> 16);
-        const unsigned nmr = nmp[(size_t)r * B];
         const float n1 = (float)(nmr & 0xffffu), n2 = (float)(nmr >> 16);
+        om[r] = nmr;
         unsigned long long abo[3], abn[3];
 #pragma unroll
         for (int b = 0; b < 3; b++) { abo[b] = __ballot((s >> (8 + b)) & 1u); abn[b] = __ballot((s >> (24 + b)) & 1u); }
         unsigned orot = s << 26, nrot = (s >> 16) << 26;     // sign of slot 2 in bit 31
-        const unsigned idx[6] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, w.z >> 16};
+        const unsigned adr[6] = {cq_addr<0>(w.x), cq_addr<1>(w.x), cq_addr<0>(w.y), cq_addr<1>(w.y), cq_addr<0>(w.z), cq_addr<1>(w.z)};
+        if (r + 1 < R) {
+          w = (tabu + (size_t)(r + 1) * B)[tid];
+          nmr = (nmu + (size_t)(r + 1) * B)[tid];
+        }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
           if (j == 5 && !ex) break;
@@ -263,13 +313,12 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           nrot = fq_shl1(nrot);
           orot = fq_shl1(orot);
           const int delta = (int)(cn - co);
-          __hip_atomic_fetch_add(&fsum[idx[j]], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(cq_lds(adr[j]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (r == 0)
           xL[tid] = cq_f(FQ_ANDOR((s >> 16) << 24, 0x80000000u, cq_u(cq_pick(n1, n2, cq_in_slot(abn, 0)))));
         if (r == R - 1)
           xR[tid + 1] = cq_f(FQ_ANDOR((s >> 16) << 25, 0x80000000u, cq_u(cq_pick(n1, n2, cq_in_slot(abn, 1)))));
-        om[r] = nmr;
         as[r] = s >> 16;
         asm volatile("" : "+v"(om[r]), "+v"(as[r]));
         __builtin_amdgcn_sched_barrier(0);
@@ -279,17 +328,9 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
 
     // ---- outputs of this frame
     if (a.bits || a.llr_out) {
-      for (int i = tid; i < a.n; i += B) {
-        const unsigned w = a.pos[i];
-        if (w == 0xffffu) continue;
-        int s = fsum[w] - FQ_BIAS;
-        if (a.bits) a.bits[base + i] = s < 0;
-        if (a.llr_out) {
-          s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);      // float_to_fix(sum), :303
-          a.llr_out[base + i] = (float)s * (1.0f / 256.0f);
-        }
-      }
       // staircase variables: posterior = q0 + the messages of the two checks (right variable of every check)
+      const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0base;
+      unsigned mask = 0;
       Open c, nx;
       open(om[0], as[0], c);
 #pragma unroll
@@ -297,16 +338,49 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         float cln;
         if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
         else cln = xL[tid + 1];
-        const unsigned v = a.chainvar[(size_t)(r + 1) * B + tid];
-        if (v != 0xffffu) {
-          int s = (int)((float)q0s[(size_t)(r + 1) * B] + c.cr + cln);
-          if (a.bits) a.bits[base + v] = s < 0;
-          if (a.llr_out) {
-            s = s > FQ_SAT ? FQ_SAT : (s < -32768 ? -32768 : s);
-            a.llr_out[base + v] = (float)s * (1.0f / 256.0f);
+        if ((wabs >> r) & 1u) {
+          const fq_u4 wr = (a.tab + (size_t)r * B)[tid];
+          if ((wr.w >> 26) & 1u) cln = 0.0f;
+        }
+        int sv = (int)((float)(q0u + (size_t)r * B)[tid] + c.cr + cln);
+        mask |= (unsigned)(sv < 0) << r;
+        if (a.llr_out) {
+          const unsigned v = a.chainvar[(size_t)r * B + tid];
+          if (v != 0xffffu) {
+            sv = sv > FQ_SAT ? FQ_SAT : (sv < -32768 ? -32768 : sv);      // float_to_fix(sum), :303
+            a.llr_out[base + v] = (float)sv * (1.0f / 256.0f);
           }
         }
         if (r + 1 < R) c = nx;
+      }
+      cbits[tid] = mask;
+      __syncthreads();
+      // hard decision of the variable with table entry p
+      auto hard = [&](const unsigned p) -> unsigned {
+        const unsigned j = p & 0x7fffu;
+        if (p & 0x8000u) return (cbits[j / R] >> (j % R)) & 1u;
+        return (unsigned)(fsum[p] - FQ_BIAS) >> 31;
+      };
+      if (vec_out) {
+        fq_u2 *o8 = (fq_u2 *)(a.bits + base);
+        for (int i = tid; i < (a.n >> 3); i += B) {
+          const fq_u4 w = pos8[i];
+          fq_u2 b;
+          b.x = hard(w.x & 0xffffu) | (hard(w.x >> 16) << 8) | (hard(w.y & 0xffffu) << 16) | (hard(w.y >> 16) << 24);
+          b.y = hard(w.z & 0xffffu) | (hard(w.z >> 16) << 8) | (hard(w.w & 0xffffu) << 16) | (hard(w.w >> 16) << 24);
+          __builtin_nontemporal_store(b, o8 + i);
+        }
+      } else if (a.bits) {
+        for (int i = tid; i < a.n; i += B) a.bits[base + i] = (uint8_t)hard(a.pos[i]);
+      }
+      if (a.llr_out) {
+        for (int i = tid; i < a.n; i += B) {
+          const unsigned p = a.pos[i];
+          if (p & 0x8000u) continue;
+          int sv = fsum[p] - FQ_BIAS;
+          sv = sv > FQ_SAT ? FQ_SAT : (sv < -32768 ? -32768 : sv);
+          a.llr_out[base + i] = (float)sv * (1.0f / 256.0f);
+        }
       }
     }
     if (a.sout) {
@@ -367,45 +441,83 @@ struct ChainQ88Engine : Engine {
         const int ca = check_of(e0), cb = check_of(e1);
         if (std::min(ca, cb) == j && std::max(ca, cb) == j + 1) { right[j] = v; is_chain[v] = 1; break; }
       }
-    std::vector<uint16_t> pos(n, 0xffff);
+    // a check without a right staircase variable may park one weight-1 variable there instead
+    // ("private": posterior = q0 + the check's own message; DVB-S2's last parity bit)
+    std::vector<char> priv(m, 0);
+    for (int j = 0; j < m; j++) {
+      if (right[j] >= 0) continue;
+      for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) {
+        const int v = c.col_idx[e];
+        if (c.col_ptr[v + 1] - c.col_ptr[v] == 1) { right[j] = v; priv[j] = 1; is_chain[v] = 1; break; }
+      }
+    }
+    // The other variables get LDS words.  Where, and in which of its slots a check visits them, is
+    // the bank-conflict schedule of the fused decoder (lds_schedule.cpp), run on the graph this
+    // kernel's LDS accesses see: check t*R + r is lane t of step r, staircase edges removed.
+    std::vector<int> rank(n, -1);
     int nl = 0;
     for (int v = 0; v < n; v++)
-      if (!is_chain[v]) pos[v] = (uint16_t)nl++;
-    dummy_base = nl;
-    words = nl + FQ_NDUMMY;
-    lds = (size_t)(words + 4 + 2 * (block + 2)) * 4;
-    if (lds > 160 * 1024 || words > 65535) {
+      if (!is_chain[v]) rank[v] = nl++;
+    ldpc_code vc;
+    vc.n = nl; vc.m = R * block; vc.q = 2;
+    vc.row_ptr.assign((size_t)vc.m + 1, 0);
+    int most = 0;
+    for (int r = 0; r < R; r++)
+      for (int t = 0; t < block; t++) {
+        const int j = t * R + r, jv = r * block + t;
+        if (j < m)
+          for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++)
+            if (rank[c.col_idx[e]] >= 0) vc.col_idx.push_back(rank[c.col_idx[e]]);
+        vc.row_ptr[jv + 1] = (int32_t)vc.col_idx.size();
+        most = std::max(most, vc.row_ptr[jv + 1] - vc.row_ptr[jv]);
+      }
+    if (most > 6) { ldpc_set_error("staircase Q8.8 decoder: more than six variables of a check outside the staircase"); return LDPC_ERR_UNSUPPORTED; }
+    const int RM = most <= 5 ? 5 : 6;
+    LdsSchedule sc;
+    int optimise = 1;
+    if (const char *e = getenv("LDPC_HIP_FUSED_PLACE")) optimise = atoi(e);
+    if (ldpc_build_lds_schedule(vc, block, RM, FQ_NDUMMY, optimise != 0, sc)) {
       ldpc_set_error("staircase Q8.8 decoder: the variables outside the staircase do not fit in LDS");
       return LDPC_ERR_UNSUPPORTED;
     }
-    std::vector<uint16_t> tab((size_t)R * block * 8, 0), chainvar((size_t)(R + 1) * block, 0xffff);
-    std::vector<uint32_t> wextra(block / 64, 0);
-    long pads = 0;
+    std::vector<uint16_t> pos(n, 0xffff);
+    for (int v = 0; v < n; v++)
+      if (rank[v] >= 0) pos[v] = sc.pos[rank[v]];
+    for (int j = 0; j < m; j++)
+      if (right[j] >= 0) pos[right[j]] = (uint16_t)(0x8000 | j);
+    dummy_base = sc.dummy_base;
+    words = sc.words;
+    lds = (size_t)(words + 4 + 2 * (block + 2) + block) * 4;
+    if (lds > 160 * 1024 || words > 0x8000) {
+      ldpc_set_error("staircase Q8.8 decoder: the variables outside the staircase do not fit in LDS");
+      return LDPC_ERR_UNSUPPORTED;
+    }
+    std::vector<uint16_t> tab((size_t)R * block * 8, 0), chainvar((size_t)R * block, 0xffff);
+    std::vector<uint32_t> wextra((size_t)block / 64 * 3, 0);
     for (int t = 0; t < block; t++)
       for (int r = 0; r < R; r++) {
         const int j = t * R + r;
         uint16_t *row = &tab[((size_t)r * block + t) * 8];
         unsigned allm = 0, flags = 0;
-        int k = 0;
-        const int lv = (j >= 1 && j < m) ? right[j - 1] : -1, rv = j < m ? right[j] : -1;
+        const int lv = (j >= 1 && j < m && !priv[j - 1]) ? right[j - 1] : -1, rv = j < m ? right[j] : -1;
         if (lv >= 0) allm |= 0x80; else flags |= 1;
         if (rv >= 0) allm |= 0x40; else flags |= 2;
-        if (r == 0) chainvar[t] = lv >= 0 ? (uint16_t)lv : 0xffff;
-        chainvar[(size_t)(r + 1) * block + t] = rv >= 0 ? (uint16_t)rv : 0xffff;
-        if (j < m)
-          for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) {
-            const int v = c.col_idx[e];
-            if (v == lv || v == rv) continue;
-            if (k >= 6) { ldpc_set_error("staircase Q8.8 decoder: more than six variables of a check outside the staircase"); return LDPC_ERR_UNSUPPORTED; }
-            row[k] = pos[v];
+        if (rv >= 0 && priv[j]) flags |= 4;
+        chainvar[(size_t)r * block + t] = rv >= 0 ? (uint16_t)rv : 0xffff;
+        if (flags & 6) wextra[t / 64 * 3 + 1] |= 1u << r;
+        if (r == 0 && lv < 0) wextra[t / 64 * 3 + 2] |= 1u;
+        for (int k = 0; k < 6; k++) {
+          if (k >= RM) { row[k] = (uint16_t)dummy_base; continue; }
+          row[k] = sc.colT[((size_t)r * RM + k) * block + t];
+          if (sc.maskT[(size_t)r * block + t] & (1u << (RM - 1 - k))) {
             allm |= 0x20u >> k;
-            k++;
+            if (k == 5) wextra[t / 64 * 3] |= 1u << r;
           }
-        if (k == 6) wextra[t / 64] |= 1u << r;
-        for (; k < 6; k++) { row[k] = (uint16_t)(dummy_base + (t * 7 + r * 13 + k * 41) % FQ_NDUMMY); pads++; }
+        }
         row[6] = 0;
         row[7] = (uint16_t)(allm | (flags << 8));
       }
+    const long pads = (long)sc.max_dummy_load * FQ_NDUMMY;
     // (a dummy word must stay "huge, positive" through the adds of one phase B: see FusedQ88Engine)
     if ((pads / FQ_NDUMMY + 1) * (long)FQ_CAP > 10000000L) {
       ldpc_set_error("staircase Q8.8 decoder: too many padded slots per dummy word");
@@ -423,7 +535,7 @@ struct ChainQ88Engine : Engine {
     HIPCHK(hipMemcpy(d_wextra.p, wextra.data(), wextra.size() * 4, hipMemcpyHostToDevice));
     hipFuncAttributes fa;
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
-    if (lds + fa.sharedSizeBytes > 160 * 1024) {
+    if (fa.sharedSizeBytes != 0 || lds > 160 * 1024) {   // (the kernel addresses its dynamic LDS from 0)
       ldpc_set_error("staircase Q8.8 decoder: frame does not fit in LDS");
       return LDPC_ERR_UNSUPPORTED;
     }
@@ -431,13 +543,13 @@ struct ChainQ88Engine : Engine {
     if (getenv("LDPC_HIP_VERBOSE")) {
       int nchain = 0;
       for (int v = 0; v < n; v++) nchain += is_chain[v];
-      fprintf(stderr, "ldpc_hip: staircase Q8.8 decoder: %d threads x %d checks, %d staircase variables in registers, %d in LDS, %zu B LDS, %d VGPRs, %zu B spilled\n",
-              block, R, nchain, nl, lds, fa.numRegs, (size_t)fa.localSizeBytes);
+      fprintf(stderr, "ldpc_hip: staircase Q8.8 decoder: %d threads x %d checks, %d staircase variables in registers, %d in LDS (%d slots per check, %ld extra LDS cycles in %ld half-wave accesses), %zu B LDS, %d VGPRs, %zu B spilled\n",
+              block, R, nchain, nl, RM, sc.conflicts, sc.accesses, lds, fa.numRegs, (size_t)fa.localSizeBytes);
     }
     return LDPC_OK;
   }
 
-  size_t q0s_bytes(long grid) const { return (size_t)grid * (R + 1) * block * sizeof(short); }
+  size_t q0s_bytes(long grid) const { return (size_t)grid * R * block * sizeof(short); }
 
   size_t nms_bytes(long grid) const { return (size_t)grid * R * block * sizeof(uint32_t); }
 

@@ -17,6 +17,9 @@ sys.path.insert(0, ROOT)
 CODES = os.path.join(ROOT, "tests", "golden", "codes")
 
 
+ITERS = int(os.environ.get("BENCH_CODES_ITERS", "10"))   # iterations executed per frame
+
+
 def main():
     import torch
     import ldpc_amd
@@ -40,6 +43,8 @@ def main():
             budget = float(os.environ.get("BENCH_CODES_BUDGET", 2.0e9 if alg.startswith("MINSUM") else 1.2e9))        # bytes of edge messages resident
             F = int(min(65536, max(256, budget // (code.E * 8))))
             F -= F % 64
+            if os.environ.get("BENCH_CODES_FRAMES"):
+                F = int(os.environ["BENCH_CODES_FRAMES"])
             gen = torch.Generator(device=dev)
             gen.manual_seed(1)
             flips = torch.rand((F, n), device=dev, generator=gen) < p
@@ -66,7 +71,7 @@ def main():
             st = torch.cuda.current_stream().cuda_stream
 
             def step():
-                dec.decode_device(F, llr.data_ptr(), dt, 10, None, bits.data_ptr(), None, None, status.data_ptr(), None, st)
+                dec.decode_device(F, llr.data_ptr(), dt, ITERS, None, bits.data_ptr(), None, None, status.data_ptr(), None, st)
             step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
