@@ -55,9 +55,13 @@ struct ChainArgs {
   float *llr_out;
   int *counter;
   int words, dummy_base;
+  unsigned long long *timing;   // [16 wavefronts][8] cycle sums per stage, or null (LDPC_HIP_FUSED_TIMING)
 };
 
 #define CQ_BIGF 16777216.0f /* 2^24 */
+#ifndef CQ_ABLATE
+#define CQ_ABLATE 0
+#endif
 #define CQ_GLOBAL __attribute__((address_space(1)))
 
 __device__ __forceinline__ float cq_pick(float a, float b, unsigned long long take_b) {
@@ -114,11 +118,16 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
   const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
   const fq_u4 *pos8 = (const fq_u4 *)a.pos;
 
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
   __syncthreads();
   for (;;) {
     const int frame = *frame_slot;
     if (frame >= a.nframes) break;
+    long long tk = a.timing ? clock64() : 0;
+    auto tick = [&](int i) {                     // (wave-uniform; a handful of scalar instructions per stage)
+      if (a.timing) { const long long now = clock64(); tacc[i] += now - tk; tk = now; }
+    };
     int next_frame = 0;
     if (tid == 0) next_frame = atomicAdd(a.counter, 1);
     const size_t base = (size_t)frame * a.n;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       }
     }
     for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;
-    unsigned sbits = 0, parbits = 0;
+    unsigned sbits = 0, parbits = 0, cmask = 0;   // cmask: hard decisions of the right variables, from the last check pass
 #pragma unroll
     for (int r = 0; r < R; r++) {
       om[r] = as[r] = 0;
@@ -168,7 +177,9 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
     }
     if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }
     for (int i = tid; i < 2 * (B + 2); i += B) xR[i] = 0.0f;
+    tick(0);
     __syncthreads();
+    tick(1);
 
     // the check in turn with its messages to the two staircase variables
     struct Open { float m1, m2, cl, cr; unsigned sgt; unsigned long long ab[3]; };
@@ -200,8 +211,9 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       Open c, nx;
       open(om[0], as[0], c);
       float Sl = left_q0(q0u) + xR[tid] + c.cl;
-      unsigned pacc = 0;
+      unsigned pacc = 0, cacc = 0;
       fq_u4 w = (tabu)[tid];
+      int q0w = q0u[tid];
       if (wabsl && ((w.w >> 24) & 1u)) Sl = CQ_BIGF;
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -213,16 +225,19 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         Sw[5] = 0;
         if (ex) Sw[5] = *cq_lds(cq_addr<1>(w.z));
         const unsigned wflags = w.w;
-        // the next check's row while this one is worked on
-        if (r + 1 < R) w = (tabu + (size_t)(r + 1) * B)[tid];
-        const float q0r = (float)(q0u + (size_t)r * B)[tid];
+        const float q0r = (float)q0w;
+        // the next check's row and channel value while this one is worked on
+        if (r + 1 < R) {
+          w = (tabu + (size_t)(r + 1) * B)[tid];
+          q0w = (q0u + (size_t)(r + 1) * B)[tid];
+        }
         float cln;
         if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
         else cln = xL[tid + 1];
-        float Sr = q0r + c.cr + cln;
+        float Sr = q0r + c.cr + cln, Sln = Sr;
         if ((wabs >> r) & 1u) {                   // (rare: wave-uniform test first)
-          if ((wflags >> 26) & 1u) Sr = q0r + c.cr;          // private variable: no second check
-          if ((wflags >> 25) & 1u) Sr = CQ_BIGF;             // no variable
+          if ((wflags >> 26) & 1u) { Sr = q0r + c.cr; Sln = CQ_BIGF; }   // private variable: no second check
+          if ((wflags >> 25) & 1u) Sr = Sln = CQ_BIGF;                   // no variable
         }
         float Sf[6];
 #pragma unroll
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         if (ex) pp ^= cq_u(Sf[5]);
         // parity of check r in bit r (after R steps; R < 32 is moved down afterwards)
         pacc = FQ_ANDOR(pp, 0x80000000u, pacc >> 1);
+        cacc = FQ_ANDOR(cq_u(Sr), 0x80000000u, cacc >> 1);   // (the pass that turns out to be the last one supplies the outputs)
         if constexpr (!PO) {
           unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, sg = c.sgt;
           auto slot = [&](const float q, const int k) {
@@ -264,20 +280,22 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           // checks below the loop and keeps every check's signs and table row alive until then
           asm volatile("" : "+v"(as[r]));
         }
-        Sl = Sr;
-        if (((wabs >> r) & 1u) && ((wflags >> 26) & 1u)) Sl = CQ_BIGF;   // (a private variable is not the next check's)
+        Sl = Sln;
         if (r + 1 < R) c = nx;
-        asm volatile("" : "+v"(pacc), "+v"(Sl));
+        asm volatile("" : "+v"(pacc), "+v"(cacc), "+v"(Sl));
         __builtin_amdgcn_sched_barrier(0);
       }
       parbits = R < 32 ? pacc >> (32 - R) : pacc;
+      cmask = R < 32 ? cacc >> (32 - R) : cacc;
     };
 
     int it_done = a.max_iter, ok = 0;
     for (int t = 1; t <= a.max_iter + 1; t++) {
       if (t == a.max_iter + 1) check_pass(std::true_type{});
       else check_pass(std::false_type{});
+      tick(2);
       const int any_bad = fq_block_or((int)(parbits ^ sbits), frame_slot + 1, t);
+      tick(3);
       if (!any_bad) { it_done = t - 1; ok = 1; break; }       // H*bits == s after iteration t-1
       if (t == a.max_iter + 1) break;
       for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (see fused_kernels.hip.h)
@@ -313,7 +331,11 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           nrot = fq_shl1(nrot);
           orot = fq_shl1(orot);
           const int delta = (int)(cn - co);
+#if CQ_ABLATE & 1   /* timing experiments only (results wrong): the fold without its LDS adds */
+          asm volatile("" ::"v"(delta), "v"(adr[j]));
+#else
           __hip_atomic_fetch_add(cq_lds(adr[j]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         }
         if (r == 0)
           xL[tid] = cq_f(FQ_ANDOR((s >> 16) << 24, 0x80000000u, cq_u(cq_pick(n1, n2, cq_in_slot(abn, 0)))));
@@ -323,43 +345,47 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         asm volatile("" : "+v"(om[r]), "+v"(as[r]));
         __builtin_amdgcn_sched_barrier(0);
       }
+      tick(4);
       __syncthreads();
+      tick(5);
     }
 
     // ---- outputs of this frame
     if (a.bits || a.llr_out) {
-      // staircase variables: posterior = q0 + the messages of the two checks (right variable of every check)
-      const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0base;
-      unsigned mask = 0;
-      Open c, nx;
-      open(om[0], as[0], c);
+      // staircase variables: the signs the last check pass saw (posterior = q0 + the messages of the
+      // two checks); their values only when the caller wants posteriors
+      if (a.llr_out) {
+        const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0base;
+        Open c, nx;
+        open(om[0], as[0], c);
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        float cln;
-        if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
-        else cln = xL[tid + 1];
-        if ((wabs >> r) & 1u) {
-          const fq_u4 wr = (a.tab + (size_t)r * B)[tid];
-          if ((wr.w >> 26) & 1u) cln = 0.0f;
-        }
-        int sv = (int)((float)(q0u + (size_t)r * B)[tid] + c.cr + cln);
-        mask |= (unsigned)(sv < 0) << r;
-        if (a.llr_out) {
+        for (int r = 0; r < R; r++) {
+          float cln;
+          if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
+          else cln = xL[tid + 1];
+          if ((wabs >> r) & 1u) {
+            const fq_u4 wr = (a.tab + (size_t)r * B)[tid];
+            if ((wr.w >> 26) & 1u) cln = 0.0f;
+          }
           const unsigned v = a.chainvar[(size_t)r * B + tid];
           if (v != 0xffffu) {
+            int sv = (int)((float)(q0u + (size_t)r * B)[tid] + c.cr + cln);
             sv = sv > FQ_SAT ? FQ_SAT : (sv < -32768 ? -32768 : sv);      // float_to_fix(sum), :303
             a.llr_out[base + v] = (float)sv * (1.0f / 256.0f);
           }
+          if (r + 1 < R) c = nx;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (r + 1 < R) c = nx;
       }
-      cbits[tid] = mask;
+      cbits[tid] = cmask;
       __syncthreads();
-      // hard decision of the variable with table entry p
+      // hard decision of the variable with table entry p: one LDS read either way
+      const unsigned cb0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned *)cbits;
       auto hard = [&](const unsigned p) -> unsigned {
         const unsigned j = p & 0x7fffu;
-        if (p & 0x8000u) return (cbits[j / R] >> (j % R)) & 1u;
-        return (unsigned)(fsum[p] - FQ_BIAS) >> 31;
+        const bool ch = (p & 0x8000u) != 0;
+        const unsigned val = (unsigned)*cq_lds(ch ? cb0 + (j / R) * 4u : j * 4u);
+        return ch ? (val >> (j % R)) & 1u : (val - (unsigned)FQ_BIAS) >> 31;
       };
       if (vec_out) {
         fq_u2 *o8 = (fq_u2 *)(a.bits + base);
@@ -394,11 +420,15 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       if (a.iters) a.iters[frame] = it_done;
       if (a.status) a.status[frame] = ok ? 0 : 1;
     }
+    tick(6);
     __syncthreads();                           // everyone has read this frame's number, sums and exchange rows
     if (tid == 0) *frame_slot = next_frame;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (see fused_q88_reg_kernel)
     __syncthreads();
+    tick(7);
   }
+  if (a.timing && (tid & 63) == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(a.timing + (tid >> 6) * 8 + i, (unsigned long long)tacc[i]);
 }
 
 }  // namespace ldpc
@@ -410,7 +440,7 @@ using namespace ldpc;
 struct ChainQ88Engine : Engine {
   int n = 0, m = 0, R = 0, block = 0, num_cu = 256, words = 0, dummy_base = 0;
   size_t lds = 0;
-  DevBuf d_tab, d_chainvar, d_pos, d_wextra, d_q0s, d_nms, d_counter;
+  DevBuf d_tab, d_chainvar, d_pos, d_wextra, d_q0s, d_nms, d_counter, d_timing;
   void (*kern)(ChainArgs) = nullptr;
 
   size_t llr_elems_per_frame() const override { return (size_t)n; }
@@ -568,11 +598,29 @@ struct ChainQ88Engine : Engine {
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
     a.counter = counter;
     a.words = words; a.dummy_base = dummy_base;
+    a.timing = nullptr;
+    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;
+    if (timing) {
+      if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
+      HIPCHK(hipMemsetAsync(d_timing.p, 0, 16 * 8 * sizeof(unsigned long long), st));
+      a.timing = d_timing.as<unsigned long long>();
+    }
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
     LAUNCHCHK("chain_q88_kernel");
     prof_end(st);
     last_iterations = max_iter;
+    if (timing) {
+      unsigned long long h[16 * 8];
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(h, d_timing.p, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "ldpc_hip: staircase kernel, cycles per wavefront summed over %ld workgroups: stage-in | barrier | check pass | barrier | fold | barrier | outputs | frame hand-over\n", grid);
+      for (int w = 0; w < block / 64; w++) {
+        fprintf(stderr, "  wave %2d:", w);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %12llu", h[w * 8 + i]);
+        fprintf(stderr, "\n");
+      }
+    }
     return LDPC_OK;
   }
 
@@ -599,9 +647,11 @@ struct ChainQ88Engine : Engine {
       ldpc_set_error("bad arguments to the staircase Q8.8 decoder");
       return LDPC_ERR_ARG;
     }
-    const long grid = std::min<long>(num_cu, nframes);
+    // as many workgroups as the scratch has rows for (each keeps R * block * 6 bytes), at most one per CU
+    long grid = std::min<long>(num_cu, nframes);
+    if (ws && ws_bytes > 512) grid = std::min<long>(grid, (long)((ws_bytes - 512) / (q0s_bytes(1) + nms_bytes(1))));
     const size_t q0b = (q0s_bytes(grid) + 255) / 256 * 256;
-    if (!ws || ws_bytes < 256 + q0b + nms_bytes(grid)) { ldpc_set_error("scratch too small for the staircase Q8.8 decoder"); return LDPC_ERR_ARG; }
+    if (!ws || grid < 1 || ws_bytes < 256 + q0b + nms_bytes(grid)) { ldpc_set_error("scratch too small for the staircase Q8.8 decoder"); return LDPC_ERR_ARG; }
     return launch((int *)ws, (short *)((char *)ws + 256), (uint32_t *)((char *)ws + 256 + q0b), grid, nframes, llr, dt, sy, max_iter, bits, iters_out, sout,
                   status, llr_out, st);
   }
