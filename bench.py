@@ -342,7 +342,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: libldpc_hip has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LDPC_BENCH_FORCE_DIST=1: take the RCCL path with one rank too (rehearsal on a one-GPU box under
+    # `python -m torch.distributed.run --nproc-per-node 1 bench.py`)
+    use_dist = world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
 
@@ -384,7 +387,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -409,7 +412,7 @@ def main():
     fails = int((status != 0).sum().item())
     undet = int(((status == 0) & (bits.any(dim=1))).sum().item())
     avg_it = float(iters.float().mean().item())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -439,7 +442,7 @@ def main():
             step2()
         fence()
         el2 = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([el2], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
@@ -514,7 +517,7 @@ def main():
             "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
