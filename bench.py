@@ -334,6 +334,12 @@ def main():
         if not args.no_cpu:
             code_n_m = np.loadtxt(args.code, max_rows=1, dtype=int)
             cpu = cpu_baseline(args, int(code_n_m[0] - code_n_m[1]))
+    elif rank == 0 and not args.pmc_child:
+        # N > 1: no child processes beside the ranks; the instruction count per launch is the
+        # committed one-GPU pass of the same workload (every rank runs that same launch)
+        counters = committed_counters(args)
+        counters_src = None if counters is None else \
+            f"committed pass {os.path.relpath(COMMITTED_COUNTERS, ROOT)} (N > 1: no live pass)"
 
     import torch
     import torch.distributed as dist
