@@ -14,11 +14,14 @@
 //     the variable between two threads' runs is exchanged (two LDS words per thread).
 //   * Only the other variables (DVB-S2 0.5: the 32 400 information bits and the last parity
 //     bit) have sums in LDS: 130 KB of the CU's 160 KB.
-//   * The compressed messages of all of a thread's checks, previous and current iteration,
-//     stay in VGPRs, three registers per check (R = 32: 96 of the 128 registers a wave of a
-//     1024-thread workgroup owns); the edge -> LDS word table (one 16-byte row per check) is
-//     re-read from L2 in both phases; the channel values of the staircase variables are parked
-//     in a per-workgroup global scratch row (int16, L2 resident) and re-read once per check.
+//   * Of the compressed messages of a thread's checks, the signs and the slot of min1 (previous
+//     and current iteration, one register per check: R = 32 of the 128 registers a wave of a
+//     1024-thread workgroup owns) stay in VGPRs; min1 | min2 live in two per-workgroup row sets in
+//     global memory (L2 / Infinity Cache) that swap roles every iteration, read a check ahead
+//     (with them in registers as well the R = 32 kernel spilled 262 registers, and every reload
+//     was a full memory wait); the edge -> LDS word table (one 16-byte row per check) is re-read
+//     from L2 in both phases; the channel values of the staircase variables are parked in a
+//     per-workgroup global row (int16) and re-read once per check.
 //
 // Slots of a check: 0 = staircase variable shared with the previous check, 1 = the one shared
 // with the next check, 2..6 = LDS variables, 7 = an optional sixth LDS variable (walked only by
@@ -43,7 +46,8 @@ struct ChainArgs {
   const uint16_t *pos;       // [n] variable -> LDS word, or 0x8000 | j: the staircase variable right of check j
   const uint32_t *wextra;    // [block / 64][3] per wavefront, bit r: some check r has slot 7 / lacks its right variable; bit 0: some check 0 lacks its left variable
   short *q0s;                // [grid][R][block] channel values of the staircase variables (right of check r)
-  uint32_t *nms;             // [grid][R][block] min1 | min2 << 16 of the current iteration, between the two phases
+  uint32_t *nms;             // [grid][2][R][block] min1 | min2 << 16 per check: two row sets per workgroup that swap roles every
+                             // iteration (the previous iteration's minima / the current one's)
   int n, m, nframes, max_iter;
   const void *llr;
   int dt;
@@ -90,6 +94,27 @@ __device__ __forceinline__ unsigned cq_addr(unsigned w) {
 // (the dynamic LDS array starts at LDS address 0: the kernel has no static LDS, which the host checks)
 __device__ __forceinline__ lds_int *cq_lds(unsigned byte_addr) { return (lds_int *)(unsigned long)byte_addr; }
 
+// The per-check rows (table, channel values, new minima) are [R][block] arrays read at row r, column
+// tid: buffer instructions take the uniform base as a descriptor, the row as a scalar byte offset and
+// the column as one 32-bit lane offset, so no row costs 64-bit vector address arithmetic or a pair of
+// address registers (global loads: two vector adds per row and access).  Reads past `bytes` return 0.
+typedef __amdgpu_buffer_rsrc_t cq_rsrc;
+__device__ __forceinline__ cq_rsrc cq_make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000 /* raw dwords, gfx9 */);
+}
+__device__ __forceinline__ fq_u4 cq_ld128(cq_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(fq_u4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ unsigned cq_ld32(cq_rsrc r, unsigned voff, unsigned soff) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ int cq_ld16s(cq_rsrc r, unsigned voff, unsigned soff) {
+  return (int)(short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void cq_st32(unsigned v, cq_rsrc r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+}
+
 // BLK: workgroup size when it is known at compile time (row offsets become constants), else 0
 template <int R, int BLK>
 __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
@@ -106,13 +131,15 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
   const unsigned wabsl = __builtin_amdgcn_readfirstlane(a.wextra[3 * (tid >> 6) + 2]);
   // (uniform bases for the loops below)
   short *q0base = a.q0s + (size_t)blockIdx.x * R * B;
-  uint32_t *nmbase = a.nms + (size_t)blockIdx.x * R * B;
+  uint32_t *nmbase = a.nms + (size_t)blockIdx.x * 2 * R * B;
+  const cq_rsrc rtab = cq_make_rsrc(a.tab, (unsigned)R * B * 16u);
+  const cq_rsrc rq0 = cq_make_rsrc(q0base, (unsigned)R * B * 2u);
+  // (the two sets of minima rows: set k of iteration t's new minima is t & 1)
+  auto nm_set = [&](int k) { return cq_make_rsrc(nmbase + (size_t)(k & 1) * R * B, (unsigned)R * B * 4u); };
 
-  // compressed messages: om = min1 | min2 << 16 of the previous iteration (the current one's waits
-  // in the global row nms between the phases: 96 registers of state did not leave the compiler
-  // enough to work with); as = signs | slot of min1 << 8, previous iteration in the low half,
-  // current in the high half (signs: slot k in bit 7 - k)
-  unsigned om[R], as[R];
+  // compressed messages: min1 | min2 << 16 in the global row sets; as = signs | slot of min1 << 8,
+  // previous iteration in the low half, current in the high half (signs: slot k in bit 7 - k)
+  unsigned as[R];
 
   const bool vec_in = a.dt == 2 && (a.n & 7) == 0 && ((size_t)a.llr & 15) == 0;
   const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
@@ -171,7 +198,8 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
     unsigned sbits = 0, parbits = 0, cmask = 0;   // cmask: hard decisions of the right variables, from the last check pass
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      om[r] = as[r] = 0;
+      as[r] = 0;
+      cq_st32(0u, nm_set(0), (unsigned)tid * 4u, (unsigned)r * B * 4u);   // "previous" minima of iteration 1: all +0
       const int c = tid * R + r;
       if (a.synd && c < a.m) sbits |= (unsigned)(a.synd[(size_t)frame * a.m + c] & 1) << r;
     }
@@ -193,27 +221,25 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       o.cr = cq_f(FQ_ANDOR(o.sgt << 1, 0x80000000u, cq_u(cq_pick(o.m1, o.m2, cq_in_slot(o.ab, 1)))));
     };
     // channel value of the variable left of the thread's first check: the previous thread's last row
-    auto left_q0 = [&](const CQ_GLOBAL short *q0u) { return (float)q0u[(size_t)(R - 1) * B + (tid ? tid - 1 : 0)]; };
+    auto left_q0 = [&]() { return (float)cq_ld16s(rq0, (unsigned)(tid ? tid - 1 : 0) * 2u, (unsigned)(R - 1) * B * 2u); };
 
     // Phase A: every check of the thread on the sums of the previous iteration.  PO: only the
     // parity of the hard decisions (the verdict after the last iteration).
-    auto check_pass = [&](auto po_c) {
+    auto check_pass = [&](auto po_c, const cq_rsrc rold, const cq_rsrc rnew) {
       constexpr bool PO = decltype(po_c)::value;
-      // (opaque copies: the table rows and channel values are loop-invariant, and hoisted out of the
-      // iteration loop they would take a hundred registers)
-      const fq_u4 *tab_ = a.tab;
-      const short *q0_ = q0base;
-      uint32_t *nm_ = nmbase;
-      asm volatile("" : "+s"(tab_), "+s"(q0_), "+s"(nm_));
-      const CQ_GLOBAL fq_u4 *tabu = (const CQ_GLOBAL fq_u4 *)tab_;
-      const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0_;
-      CQ_GLOBAL uint32_t *nmu = (CQ_GLOBAL uint32_t *)nm_;
+      // (an opaque lane offset: the table rows and channel values are loop-invariant, and hoisted out
+      // of the iteration loop they would take a hundred registers)
+      unsigned t16 = (unsigned)tid * 16u;
+      asm volatile("" : "+v"(t16));
+      const unsigned t2 = t16 >> 3, t4 = t16 >> 2;
       Open c, nx;
-      open(om[0], as[0], c);
-      float Sl = left_q0(q0u) + xR[tid] + c.cl;
+      unsigned omn = cq_ld32(rold, t4, 0);
+      fq_u4 w = cq_ld128(rtab, t16, 0);
+      int q0w = cq_ld16s(rq0, t2, 0);
+      open(omn, as[0], c);
+      if (R > 1) omn = cq_ld32(rold, t4, (unsigned)B * 4u);      // (of check r + 1, a check ahead of its use)
+      float Sl = left_q0() + xR[tid] + c.cl;
       unsigned pacc = 0, cacc = 0;
-      fq_u4 w = (tabu)[tid];
-      int q0w = q0u[tid];
       if (wabsl && ((w.w >> 24) & 1u)) Sl = CQ_BIGF;
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -228,12 +254,15 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         const float q0r = (float)q0w;
         // the next check's row and channel value while this one is worked on
         if (r + 1 < R) {
-          w = (tabu + (size_t)(r + 1) * B)[tid];
-          q0w = (q0u + (size_t)(r + 1) * B)[tid];
+          w = cq_ld128(rtab, t16, (unsigned)(r + 1) * B * 16u);
+          q0w = cq_ld16s(rq0, t2, (unsigned)(r + 1) * B * 2u);
         }
         float cln;
-        if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
-        else cln = xL[tid + 1];
+        if (r + 1 < R) {
+          open(omn, as[r + 1], nx);
+          cln = nx.cl;
+          if (r + 2 < R) omn = cq_ld32(rold, t4, (unsigned)(r + 2) * B * 4u);
+        } else cln = xL[tid + 1];
         float Sr = q0r + c.cr + cln, Sln = Sr;
         if ((wabs >> r) & 1u) {                   // (rare: wave-uniform test first)
           if ((wflags >> 26) & 1u) { Sr = q0r + c.cr; Sln = CQ_BIGF; }   // private variable: no second check
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           // (non-negative floats order like their bit patterns: the clamp is an integer minimum)
           const float n1 = cq_f(min(k1 & ~7u, 0x46fe0000u /* 127.0 * 256 */));
           const float n2 = cq_f(min(k2 & ~7u, 0x46fe0000u));
-          (nmu + (size_t)r * B)[tid] = (unsigned)n1 | ((unsigned)n2 << 16);
+          cq_st32((unsigned)n1 | ((unsigned)n2 << 16), rnew, t4, (unsigned)r * B * 4u);
           as[r] = (as[r] & 0xffffu) | ((nsg | ((k1 & 7u) << 8)) << 16);
           // materialise the new state here: left alone the compiler sinks this arithmetic of all R
           // checks below the loop and keeps every check's signs and table row alive until then
@@ -289,10 +318,12 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       cmask = R < 32 ? cacc >> (32 - R) : cacc;
     };
 
-    int it_done = a.max_iter, ok = 0;
+    int it_done = a.max_iter, ok = 0, t_last = 1;
     for (int t = 1; t <= a.max_iter + 1; t++) {
-      if (t == a.max_iter + 1) check_pass(std::true_type{});
-      else check_pass(std::false_type{});
+      const cq_rsrc rold = nm_set(t - 1), rnew = nm_set(t);
+      t_last = t;
+      if (t == a.max_iter + 1) check_pass(std::true_type{}, rold, rnew);
+      else check_pass(std::false_type{}, rold, rnew);
       tick(2);
       const int any_bad = fq_block_or((int)(parbits ^ sbits), frame_slot + 1, t);
       tick(3);
@@ -300,28 +331,26 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       if (t == a.max_iter + 1) break;
       for (int i = a.dummy_base + tid; i < a.words; i += B) fsum[i] = FQ_BIG;   // re-arm (see fused_kernels.hip.h)
       // ---- phase B: the new messages replace the old ones in the LDS sums
-      const fq_u4 *tab_ = a.tab;
-      const uint32_t *nm_ = nmbase;
-      asm volatile("" : "+s"(tab_), "+s"(nm_));
-      const CQ_GLOBAL fq_u4 *tabu = (const CQ_GLOBAL fq_u4 *)tab_;
-      const CQ_GLOBAL uint32_t *nmu = (const CQ_GLOBAL uint32_t *)nm_;
-      fq_u4 w = tabu[tid];
-      unsigned nmr = nmu[tid];
+      unsigned t16 = (unsigned)tid * 16u;
+      asm volatile("" : "+v"(t16));
+      const unsigned t4 = t16 >> 2;
+      fq_u4 w = cq_ld128(rtab, t16, 0);
+      unsigned nmr = cq_ld32(rnew, t4, 0), omr = cq_ld32(rold, t4, 0);
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const bool ex = (wex >> r) & 1u;
         const unsigned s = as[r];
-        const float o1 = (float)(om[r] & 0xffffu), o2 = (float)(om[r] >> 16);
+        const float o1 = (float)(omr & 0xffffu), o2 = (float)(omr >> 16);
         const float n1 = (float)(nmr & 0xffffu), n2 = (float)(nmr >> 16);
-        om[r] = nmr;
         unsigned long long abo[3], abn[3];
 #pragma unroll
         for (int b = 0; b < 3; b++) { abo[b] = __ballot((s >> (8 + b)) & 1u); abn[b] = __ballot((s >> (24 + b)) & 1u); }
         unsigned orot = s << 26, nrot = (s >> 16) << 26;     // sign of slot 2 in bit 31
         const unsigned adr[6] = {cq_addr<0>(w.x), cq_addr<1>(w.x), cq_addr<0>(w.y), cq_addr<1>(w.y), cq_addr<0>(w.z), cq_addr<1>(w.z)};
         if (r + 1 < R) {
-          w = (tabu + (size_t)(r + 1) * B)[tid];
-          nmr = (nmu + (size_t)(r + 1) * B)[tid];
+          w = cq_ld128(rtab, t16, (unsigned)(r + 1) * B * 16u);
+          nmr = cq_ld32(rnew, t4, (unsigned)(r + 1) * B * 4u);
+          omr = cq_ld32(rold, t4, (unsigned)(r + 1) * B * 4u);
         }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         if (r == R - 1)
           xR[tid + 1] = cq_f(FQ_ANDOR((s >> 16) << 25, 0x80000000u, cq_u(cq_pick(n1, n2, cq_in_slot(abn, 1)))));
         as[r] = s >> 16;
-        asm volatile("" : "+v"(om[r]), "+v"(as[r]));
+        asm volatile("" : "+v"(as[r]));
         __builtin_amdgcn_sched_barrier(0);
       }
       tick(4);
@@ -355,13 +384,14 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       // staircase variables: the signs the last check pass saw (posterior = q0 + the messages of the
       // two checks); their values only when the caller wants posteriors
       if (a.llr_out) {
-        const CQ_GLOBAL short *q0u = (const CQ_GLOBAL short *)q0base;
+        // (the messages in effect are the "previous" ones of the last check pass)
+        const cq_rsrc rold = nm_set(t_last - 1);
         Open c, nx;
-        open(om[0], as[0], c);
+        open(cq_ld32(rold, (unsigned)tid * 4u, 0), as[0], c);
 #pragma unroll
         for (int r = 0; r < R; r++) {
           float cln;
-          if (r + 1 < R) { open(om[r + 1], as[r + 1], nx); cln = nx.cl; }
+          if (r + 1 < R) { open(cq_ld32(rold, (unsigned)tid * 4u, (unsigned)(r + 1) * B * 4u), as[r + 1], nx); cln = nx.cl; }
           else cln = xL[tid + 1];
           if ((wabs >> r) & 1u) {
             const fq_u4 wr = (a.tab + (size_t)r * B)[tid];
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           }
           const unsigned v = a.chainvar[(size_t)r * B + tid];
           if (v != 0xffffu) {
-            int sv = (int)((float)(q0u + (size_t)r * B)[tid] + c.cr + cln);
+            int sv = (int)((float)cq_ld16s(rq0, (unsigned)tid * 2u, (unsigned)r * B * 2u) + c.cr + cln);
             sv = sv > FQ_SAT ? FQ_SAT : (sv < -32768 ? -32768 : sv);      // float_to_fix(sum), :303
             a.llr_out[base + v] = (float)sv * (1.0f / 256.0f);
           }
@@ -581,7 +611,7 @@ struct ChainQ88Engine : Engine {
 
   size_t q0s_bytes(long grid) const { return (size_t)grid * R * block * sizeof(short); }
 
-  size_t nms_bytes(long grid) const { return (size_t)grid * R * block * sizeof(uint32_t); }
+  size_t nms_bytes(long grid) const { return (size_t)grid * 2 * R * block * sizeof(uint32_t); }
 
   int launch(int *counter, short *q0s, uint32_t *nms, long grid, int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter,
              uint8_t *bits, int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out, hipStream_t st) {
@@ -638,7 +668,7 @@ struct ChainQ88Engine : Engine {
                   status, llr_out, st);
   }
 
-  // scratch: the frame queue head (256 B), the channel rows of the staircase variables, the rows of new minima
+  // scratch: the frame queue head (256 B), the channel rows of the staircase variables, the two sets of minima rows
   int decode_ws(void *ws, size_t ws_bytes, int nframes, const void *llr, int dt, const uint8_t *sy, int max_iter,
                 uint8_t *bits, int32_t *iters_out, uint8_t *sout, int32_t *status, float *llr_out,
                 hipStream_t st) override {
@@ -647,7 +677,7 @@ struct ChainQ88Engine : Engine {
       ldpc_set_error("bad arguments to the staircase Q8.8 decoder");
       return LDPC_ERR_ARG;
     }
-    // as many workgroups as the scratch has rows for (each keeps R * block * 6 bytes), at most one per CU
+    // as many workgroups as the scratch has rows for (each keeps R * block * 10 bytes), at most one per CU
     long grid = std::min<long>(num_cu, nframes);
     if (ws && ws_bytes > 512) grid = std::min<long>(grid, (long)((ws_bytes - 512) / (q0s_bytes(1) + nms_bytes(1))));
     const size_t q0b = (q0s_bytes(grid) + 255) / 256 * 256;
