@@ -81,6 +81,13 @@ __device__ __forceinline__ unsigned long long cq_in_slot(const unsigned long lon
   return m;
 }
 __device__ __forceinline__ float cq_f(unsigned x) { return __uint_as_float(x); }
+// bit r of a wave-uniform word, tested where it is used: computed ahead of the unrolled loops (as
+// the compiler does when left alone) the 32 x 3 answers become 64-bit lane masks in spilled scalar
+// registers, and every test two v_readlane
+__device__ __forceinline__ bool cq_bit(unsigned word, const int r) {
+  asm volatile("" : "+s"(word));
+  return (word >> r) & 1u;
+}
 __device__ __forceinline__ unsigned cq_u(float x) { return __float_as_uint(x); }
 
 // LDS byte address of one of the two 16-bit word indices packed in w: one SDWA shift
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       if (wabsl && ((w.w >> 24) & 1u)) Sl = CQ_BIGF;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const bool ex = (wex >> r) & 1u;          // (wave-uniform)
+        const bool ex = cq_bit(wex, r);           // (wave-uniform)
         int Sw[6];
         Sw[0] = *cq_lds(cq_addr<0>(w.x)); Sw[1] = *cq_lds(cq_addr<1>(w.x));
         Sw[2] = *cq_lds(cq_addr<0>(w.y)); Sw[3] = *cq_lds(cq_addr<1>(w.y));
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           if (r + 2 < R) omn = cq_ld32(rold, t4, (unsigned)(r + 2) * B * 4u);
         } else cln = xL[tid + 1];
         float Sr = q0r + c.cr + cln, Sln = Sr;
-        if ((wabs >> r) & 1u) {                   // (rare: wave-uniform test first)
+        if (cq_bit(wabs, r)) {                    // (rare: wave-uniform test first)
           if ((wflags >> 26) & 1u) { Sr = q0r + c.cr; Sln = CQ_BIGF; }   // private variable: no second check
           if ((wflags >> 25) & 1u) Sr = Sln = CQ_BIGF;                   // no variable
         }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       unsigned nmr = cq_ld32(rnew, t4, 0), omr = cq_ld32(rold, t4, 0);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const bool ex = (wex >> r) & 1u;
+        const bool ex = cq_bit(wex, r);
         const unsigned s = as[r];
         const float o1 = (float)(omr & 0xffffu), o2 = (float)(omr >> 16);
         const float n1 = (float)(nmr & 0xffffu), n2 = (float)(nmr >> 16);
