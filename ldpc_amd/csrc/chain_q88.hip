@@ -101,6 +101,14 @@ __device__ __forceinline__ unsigned cq_addr(unsigned w) {
 // (the dynamic LDS array starts at LDS address 0: the kernel has no static LDS, which the host checks)
 __device__ __forceinline__ lds_int *cq_lds(unsigned byte_addr) { return (lds_int *)(unsigned long)byte_addr; }
 
+// as: byte 2 <- the low byte of signs, byte 3 <- slot & 7, the low half kept (two SDWA writes
+// instead of mask, shift, and-or, shift-or)
+__device__ __forceinline__ unsigned cq_set_new(unsigned as, const unsigned signs, const unsigned key) {
+  asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(as) : "v"(signs));
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(as) : "v"(key), "v"(7u));
+  return as;
+}
+
 // The per-check rows (table, channel values, new minima) are [R][block] arrays read at row r, column
 // tid: buffer instructions take the uniform base as a descriptor, the row as a scalar byte offset and
 // the column as one 32-bit lane offset, so no row costs 64-bit vector address arithmetic or a pair of
@@ -208,7 +216,9 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       as[r] = 0;
       cq_st32(0u, nm_set(0), (unsigned)tid * 4u, (unsigned)r * B * 4u);   // "previous" minima of iteration 1: all +0
       const int c = tid * R + r;
-      if (a.synd && c < a.m) sbits |= (unsigned)(a.synd[(size_t)frame * a.m + c] & 1) << r;
+      // (per-check bit words -- syndrome, parity, hard decisions -- hold check r in bit R - 1 - r:
+      // the accumulators of the check pass shift left, one v_alignbit per check)
+      if (a.synd && c < a.m) sbits |= (unsigned)(a.synd[(size_t)frame * a.m + c] & 1) << (R - 1 - r);
     }
     if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }
     for (int i = tid; i < 2 * (B + 2); i += B) xR[i] = 0.0f;
@@ -245,9 +255,12 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
       int q0w = cq_ld16s(rq0, t2, 0);
       open(omn, as[0], c);
       if (R > 1) omn = cq_ld32(rold, t4, (unsigned)B * 4u);      // (of check r + 1, a check ahead of its use)
-      float Sl = left_q0() + xR[tid] + c.cl;
+      // vl: message of the variable left of the check in turn (q0 + the message of the check on its
+      // other side), Sl: its posterior
+      float vl = left_q0() + xR[tid];
       unsigned pacc = 0, cacc = 0;
-      if (wabsl && ((w.w >> 24) & 1u)) Sl = CQ_BIGF;
+      if (wabsl && ((w.w >> 24) & 1u)) vl = CQ_BIGF;
+      float Sl = vl + c.cl;
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const bool ex = cq_bit(wex, r);           // (wave-uniform)
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         Sw[0] = *cq_lds(cq_addr<0>(w.x)); Sw[1] = *cq_lds(cq_addr<1>(w.x));
         Sw[2] = *cq_lds(cq_addr<0>(w.y)); Sw[3] = *cq_lds(cq_addr<1>(w.y));
         Sw[4] = *cq_lds(cq_addr<0>(w.z));
-        Sw[5] = 0;
+        Sw[5] = FQ_BIAS;                            // (reads as +0.0 below: no sign, no parity)
         if (ex) Sw[5] = *cq_lds(cq_addr<1>(w.z));
         const unsigned wflags = w.w;
         const float q0r = (float)q0w;
@@ -270,10 +283,12 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
           cln = nx.cl;
           if (r + 2 < R) omn = cq_ld32(rold, t4, (unsigned)(r + 2) * B * 4u);
         } else cln = xL[tid + 1];
-        float Sr = q0r + c.cr + cln, Sln = Sr;
+        // the variable right of the check: its message to this check, its posterior, its message to
+        // the next check (integer-valued floats: exact in any order)
+        float vr = q0r + cln, Sr = vr + c.cr, vln = q0r + c.cr, Sln = Sr;
         if (cq_bit(wabs, r)) {                    // (rare: wave-uniform test first)
-          if ((wflags >> 26) & 1u) { Sr = q0r + c.cr; Sln = CQ_BIGF; }   // private variable: no second check
-          if ((wflags >> 25) & 1u) Sr = Sln = CQ_BIGF;                   // no variable
+          if ((wflags >> 26) & 1u) { vr = q0r; Sr = vln; vln = Sln = CQ_BIGF; }   // private variable: no second check
+          if ((wflags >> 25) & 1u) vr = Sr = vln = Sln = CQ_BIGF;                 // no variable
         }
         float Sf[6];
 #pragma unroll
@@ -281,10 +296,10 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         unsigned pp = __builtin_amdgcn_bitop3_b32(cq_u(Sl), cq_u(Sr), cq_u(Sf[0]), 0x96);
         pp = __builtin_amdgcn_bitop3_b32(pp, cq_u(Sf[1]), cq_u(Sf[2]), 0x96);
         pp = __builtin_amdgcn_bitop3_b32(pp, cq_u(Sf[3]), cq_u(Sf[4]), 0x96);
-        if (ex) pp ^= cq_u(Sf[5]);
-        // parity of check r in bit r (after R steps; R < 32 is moved down afterwards)
-        pacc = FQ_ANDOR(pp, 0x80000000u, pacc >> 1);
-        cacc = FQ_ANDOR(cq_u(Sr), 0x80000000u, cacc >> 1);   // (the pass that turns out to be the last one supplies the outputs)
+        pp ^= cq_u(Sf[5]);
+        // parity of check r in bit R - 1 - r after R steps
+        pacc = __builtin_amdgcn_alignbit(pacc, pp, 31);
+        cacc = __builtin_amdgcn_alignbit(cacc, cq_u(Sr), 31);   // (the pass that turns out to be the last one supplies the outputs)
         if constexpr (!PO) {
           unsigned k1 = 0xffffffffu, k2 = 0xffffffffu, sg = c.sgt;
           auto slot = [&](const float q, const int k) {
@@ -293,8 +308,8 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
             k2 = fq_med3u(k1, key, k2);
             k1 = min(k1, key);
           };
-          slot(Sl - c.cl, 0);
-          slot(Sr - c.cr, 1);
+          slot(vl, 0);
+          slot(vr, 1);
 #pragma unroll
           for (int j = 0; j < 6; j++) {
             if (j == 5 && !ex) { sg <<= 1; break; }
@@ -302,27 +317,30 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
             slot(Sf[j] - cq_f(FQ_ANDOR(sg, 0x80000000u, cq_u(mo))), 2 + j);
           }
           // sgnprod = s ^ XOR(signs); c2v_k < 0 iff sgnprod != sign_k (:278-283)
-          const unsigned tot = (unsigned)__popc(sg) + (sbits >> r);
+          const unsigned tot = (unsigned)__popc(sg) + (sbits >> (R - 1 - r));
           const unsigned flip = (unsigned)(-(int)(tot & 1u));
           const unsigned allm = (wflags >> 16) & 0xffu;
           const unsigned nsg = __builtin_amdgcn_bitop3_b32(sg, allm, flip, 0x78);   // sg ^ (allm & flip)
           // min over saturated magnitudes = saturated min (:43-53, :269-277)
           // (non-negative floats order like their bit patterns: the clamp is an integer minimum)
-          const float n1 = cq_f(min(k1 & ~7u, 0x46fe0000u /* 127.0 * 256 */));
-          const float n2 = cq_f(min(k2 & ~7u, 0x46fe0000u));
+          // (the slot number in a key's low bits is a fraction of the values below the cap -- integers
+          // under 2^15 -- and the conversion truncates it)
+          const float n1 = cq_f(min(k1, 0x46fe0000u /* 127.0 * 256 */));
+          const float n2 = cq_f(min(k2, 0x46fe0000u));
           cq_st32((unsigned)n1 | ((unsigned)n2 << 16), rnew, t4, (unsigned)r * B * 4u);
-          as[r] = (as[r] & 0xffffu) | ((nsg | ((k1 & 7u) << 8)) << 16);
+          as[r] = cq_set_new(as[r], nsg, k1);
           // materialise the new state here: left alone the compiler sinks this arithmetic of all R
           // checks below the loop and keeps every check's signs and table row alive until then
           asm volatile("" : "+v"(as[r]));
         }
         Sl = Sln;
+        vl = vln;
         if (r + 1 < R) c = nx;
-        asm volatile("" : "+v"(pacc), "+v"(cacc), "+v"(Sl));
+        asm volatile("" : "+v"(pacc), "+v"(cacc), "+v"(Sl), "+v"(vl));
         __builtin_amdgcn_sched_barrier(0);
       }
-      parbits = R < 32 ? pacc >> (32 - R) : pacc;
-      cmask = R < 32 ? cacc >> (32 - R) : cacc;
+      parbits = pacc;
+      cmask = cacc;
     };
 
     int it_done = a.max_iter, ok = 0, t_last = 1;
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
         const unsigned j = p & 0x7fffu;
         const bool ch = (p & 0x8000u) != 0;
         const unsigned val = (unsigned)*cq_lds(ch ? cb0 + (j / R) * 4u : j * 4u);
-        return ch ? (val >> (j % R)) & 1u : (val - (unsigned)FQ_BIAS) >> 31;
+        return ch ? (val >> (R - 1 - j % R)) & 1u : (val - (unsigned)FQ_BIAS) >> 31;
       };
       if (vec_out) {
         fq_u2 *o8 = (fq_u2 *)(a.bits + base);
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(1024) void chain_q88_kernel(ChainArgs a) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const int cc = tid * R + r;
-        if (cc < a.m) a.sout[(size_t)frame * a.m + cc] = (uint8_t)((parbits >> r) & 1u);
+        if (cc < a.m) a.sout[(size_t)frame * a.m + cc] = (uint8_t)((parbits >> (R - 1 - r)) & 1u);
       }
     }
     if (tid == 0) {
