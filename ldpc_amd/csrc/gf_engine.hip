@@ -383,6 +383,169 @@ __global__ __launch_bounds__(1024) void gf2p_vn_lds_kernel(GGraph g, WTab tab, i
   }
 }
 
+// ---- the LDS-table kernels again, specialised for GF(4) / GF(8) (LQ = log2 Q at compile time)
+//
+// Same layout, same arithmetic, same results as gf2p_*_lds_kernel; what changes is what the
+// generic kernels spend their instructions on (about 280 per edge and lane, against some 60 of
+// table arithmetic): the field order as a run-time value (butterfly, arg-max and lane arithmetic as
+// loops and divisions), a 64-bit division per work item, two gathers into the multiplication table
+// per edge, and the data-dependent branches of Flog.  Here the butterflies unroll to DPP moves, a
+// lane keeps its row of the multiplication table in a register pair (a byte per coefficient), a
+// work item advances by additions, rows are addressed as uniform base + lane offset, Flog / Fexp
+// select instead of branching (the one branch left hands the 2e-4 of arguments next to a rounding
+// boundary back to the full table), and a check's intermediate values stay in registers -- so a
+// workgroup needs the 80 KiB image and nothing else, and two of them share a CU.
+__device__ __forceinline__ int w_fexp_q(const uint32_t *img, int x) {
+  x = x < -W_LEVELS ? -W_LEVELS : x;
+  x = x > W_LEVELS - 1 ? W_LEVELS - 1 : x;
+  const int e = x >> W_DECI, fr = x & (kWhtFrac - 1);
+  const int sh = 18 - e;                                   // >= 1 unless x > 17 * kWhtFrac
+  const int shc = sh < 1 ? 1 : sh;
+  const unsigned long long Y = (1ull << 32) | img[W_IMG_XEXP + fr];
+  const unsigned v = (unsigned)((Y + (1ull << ((shc - 1) & 63))) >> (shc & 63));
+  const int r = sh >= 34 ? 0 : (int)v;
+  return x > 17 * kWhtFrac ? (int)(1u << 31) : r;
+}
+__device__ __forceinline__ int w_flog_q(const uint32_t *img, const WTab &t, const int x) {
+  const int xs = x < 1 ? 1 : x;
+  const int e0 = 31 - __clz(xs);
+  const int i = e0 > 19 ? e0 - 19 : 0;                     // while (x >= LEVELS) x >>= 1, :242
+  const int xx = xs >> i;
+  const bool small = xx < kWhtSmall;
+  const int vs = (int)img[W_IMG_SMALL + (small ? xx : kWhtSmall - 1)];
+  const int xc = small ? kWhtSmall : xx;                   // (the segment form serves 2048 and up)
+  const int e = 31 - __clz(xc);
+  const int r = xc - (1 << e), sh = e - 9;
+  const int h = r >> sh, lo = r & ((1 << sh) - 1);
+  const float u = ldexpf((float)lo, -e) - 0x1p-10f;
+  const w_f4 q = *(const w_f4 *)(img + W_IMG_SEG + 4 * h);
+  const float w = fmaf(u, fmaf(u, q.z, q.y), q.x);
+  const float fl = floorf(w + 0.5f);
+  int v = __float_as_int(q.w) + W_FMUL * (e - 14) + (int)fl;
+  if (!small && fabsf(w - fl) > 0.5f - 1e-4f) v = t.flog[xx];   // too close to a rounding boundary: the full table decides
+  v = small ? vs : v;
+  v += i << W_DECI;
+  return x <= 0 ? -W_FMUL * 14 : v;
+}
+template <int LQ>
+__device__ __forceinline__ int wht_q(int y, const int a) {
+#pragma unroll
+  for (int b = 0; b < LQ; b++) {
+    const int partner = __shfl_xor(y, 1 << b);
+    y = (a & (1 << b)) ? partner - y : y + partner;
+  }
+  return y;
+}
+// work items (node, frame group) of a persistent workgroup: wavefront w of block b starts at
+// b * nw + w and advances by gridDim * nw, as (node, group) pairs without a division per item
+struct ItemWalk {
+  unsigned node, fg, dnode, dfg, nfg;
+  __device__ __forceinline__ ItemWalk(unsigned first, unsigned stride, unsigned nfg_) : nfg(nfg_) {
+    node = first / nfg; fg = first - node * nfg;
+    dnode = stride / nfg; dfg = stride - dnode * nfg;
+  }
+  __device__ __forceinline__ void next() {
+    node += dnode; fg += dfg;
+    if (fg >= nfg) { fg -= nfg; node++; }
+  }
+};
+
+template <int LQ, int PF>   // row weights <= PF
+__global__ __launch_bounds__(1024) void gf2p_cn_q_kernel(GGraph g, WTab tab, int nfg, int dcmax,
+                                                         const int *__restrict__ qa, int *__restrict__ ra,
+                                                         const uint8_t *__restrict__ synd) {
+  constexpr int Q = 1 << LQ, G = 64 / Q, half = LQ / 2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t w_lds[];
+  w_load_image(w_lds, tab);
+  const int l = threadIdx.x & 63, a = l & (Q - 1), base = l & ~(Q - 1), gi = l >> LQ;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  unsigned long long mrow = 0;                             // a * h for every coefficient h, a byte each
+#pragma unroll
+  for (int h = 0; h < Q; h++) mrow |= (unsigned long long)g.mul[a * Q + h] << (8 * h);
+  const size_t row = (size_t)g.Fpad * Q;                   // values per edge
+  for (ItemWalk it(blockIdx.x * nw + wave, gridDim.x * nw, (unsigned)nfg); it.node < (unsigned)g.m; it.next()) {
+    const int j = (int)it.node;
+    const unsigned lo = it.fg * 64u + (unsigned)l;         // (fg * G + gi) * Q + a
+    const int p0 = g.row_ptr[j], dc = g.row_ptr[j + 1] - p0;
+    const int z = synd ? synd[(size_t)j * g.Fpad + it.fg * G + gi] : 0;
+    int pre[PF], pk[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) pre[k] = k < dc ? (qa + (size_t)(p0 + k) * row)[lo] : 0;
+    int logprod = 0, sgnsum = 0;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+      if (k >= dc) break;
+      const int x = w_fexp_q(w_lds, pre[k]);
+      const int hi = g.hinv[p0 + k];
+      int y = __shfl(x, base + (int)((mrow >> (8 * hi)) & 0xffu));
+      y = wht_q<LQ>(y, a);
+      const int neg = y < 0;
+      y = neg ? -y : y;
+      sgnsum ^= neg;
+      if (half > 0) y = (y + (1 << (half > 0 ? half - 1 : 0))) >> half;
+      const int lg = w_flog_q(w_lds, tab, y);
+      pk[k] = lg * 2 + neg;
+      logprod += lg;
+    }
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+      if (k >= dc) break;
+      int r = w_fexp_q(w_lds, logprod - (pk[k] >> 1) + LQ * W_FMUL);
+      if ((pk[k] & 1) != sgnsum) r = -r;
+      r = wht_q<LQ>(r, a);
+      const int hv = g.hval[p0 + k];
+      const int t = __shfl(r, base + (z ^ (int)((mrow >> (8 * hv)) & 0xffu)));
+      (ra + (size_t)(p0 + k) * row)[lo] = w_flog_q(w_lds, tab, t);
+    }
+  }
+}
+
+template <int LQ, int PF>   // column weights <= PF
+__global__ __launch_bounds__(1024) void gf2p_vn_q_kernel(GGraph g, WTab tab, int nfg, const int *__restrict__ fna,
+                                                         const int *__restrict__ ra, int *__restrict__ qa,
+                                                         uint8_t *__restrict__ xhat,
+                                                         const uint8_t *__restrict__ frozen) {
+  constexpr int Q = 1 << LQ, G = 64 / Q;
+  extern __shared__ __attribute__((aligned(16))) uint32_t w_lds[];
+  w_load_image(w_lds, tab);
+  const int l = threadIdx.x & 63, a = l & (Q - 1), base = l & ~(Q - 1), gi = l >> LQ;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  const size_t row = (size_t)g.Fpad * Q;
+  for (ItemWalk it(blockIdx.x * nw + wave, gridDim.x * nw, (unsigned)nfg); it.node < (unsigned)g.n; it.next()) {
+    const int i = (int)it.node;
+    const unsigned lo = it.fg * 64u + (unsigned)l;
+    const int p0 = g.col_ptr[i], dv = g.col_ptr[i + 1] - p0;
+    int logprod = (fna + (size_t)i * row)[lo];
+    int pre[PF], pe[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+      pe[k] = k < dv ? g.edge_of[p0 + k] : 0;
+      pre[k] = k < dv ? (ra + (size_t)pe[k] * row)[lo] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < PF; k++) logprod += pre[k];
+    int maxp = -(1 << 30), arg = -1;                       // first maximum wins (strict >), :496-503
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+      const int v = __shfl(logprod, base + t);
+      if (v > maxp) { maxp = v; arg = t; }
+    }
+    const unsigned f = it.fg * G + (unsigned)gi;
+    if (a == 0 && !frozen[f]) xhat[(size_t)i * g.Fpad + f] = (uint8_t)arg;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+      if (k >= dv) break;
+      int q = logprod - pre[k];
+      int sum = w_fexp_q(w_lds, q);
+#pragma unroll
+      for (int b = 0; b < LQ; b++) sum += __shfl_xor(sum, 1 << b);
+      if (sum <= 0) sum = Q;
+      q -= w_flog_q(w_lds, tab, sum);
+      (qa + (size_t)pe[k] * row)[lo] = q;
+    }
+  }
+}
+
 // ------------------------------------------------ GF(q) direct check node
 //
 // One wave per (check j, G frames).  GFq_LDPC.c:369-424: rho backward (kept in
@@ -683,6 +846,9 @@ struct GfEngine : Engine {
   bool lds_tables = false;   // GF2P_WHT: compact tables in LDS (gf2p_*_lds_kernel)
   void (*cn_lds_kern)(GGraph, WTab, int, int, const int *, int *, const uint8_t *) = nullptr;
   void (*vn_lds_kern)(GGraph, WTab, int, const int *, const int *, int *, uint8_t *, const uint8_t *) = nullptr;
+  // GF(4) / GF(8) with row and column weights <= 8: the specialised kernels (gf2p_*_q_kernel), two workgroups per CU
+  void (*cn_q_kern)(GGraph, WTab, int, int, const int *, int *, const uint8_t *) = nullptr;
+  void (*vn_q_kern)(GGraph, WTab, int, const int *, const int *, int *, uint8_t *, const uint8_t *) = nullptr;
   int cn_waves = 0, num_cu = 256;
   DevBuf fna, qa, ra, xhat, zhat, synd, st_i32, st_frozen, remaining;
   int32_t *h_remaining = nullptr;
@@ -806,6 +972,18 @@ struct GfEngine : Engine {
                                    (int)(img_bytes + cn_waves * row_bytes)));
         HIPCHK(hipFuncSetAttribute((const void *)vn_lds_kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)img_bytes));
+        // LDPC_HIP_GF_LDS_TABLES=2 keeps the generic LDS-table kernels for these shapes as well
+        if (env_c == 1 && (log2q == 2 || log2q == 3) && rmax <= 8 && c.cmax <= 8) {
+          if (log2q == 2) {
+            cn_q_kern = rmax <= 4 ? gf2p_cn_q_kernel<2, 4> : gf2p_cn_q_kernel<2, 8>;
+            vn_q_kern = c.cmax <= 4 ? gf2p_vn_q_kernel<2, 4> : gf2p_vn_q_kernel<2, 8>;
+          } else {
+            cn_q_kern = rmax <= 4 ? gf2p_cn_q_kernel<3, 4> : gf2p_cn_q_kernel<3, 8>;
+            vn_q_kern = c.cmax <= 4 ? gf2p_vn_q_kernel<3, 4> : gf2p_vn_q_kernel<3, 8>;
+          }
+          HIPCHK(hipFuncSetAttribute((const void *)cn_q_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes));
+          HIPCHK(hipFuncSetAttribute((const void *)vn_q_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes));
+        }
       }
     }
     const size_t per = (size_t)Fpad_max * Q * sizeof(T);
@@ -918,7 +1096,11 @@ struct GfEngine : Engine {
     for (int t = 0; t < max_iter; t++) {
       prof_begin(K_CN, st);
       if constexpr (WHT) {
-        if (lds_tables) {
+        if (lds_tables && cn_q_kern && (size_t)std::max(m, n) * nfg < (1u << 31)) {
+          const size_t want = ((size_t)m * nfg + 15) / 16;
+          hipLaunchKernelGGL(cn_q_kern, dim3((unsigned)std::min<size_t>(want, (size_t)2 * num_cu)), dim3(1024),
+                             (size_t)W_IMAGE_WORDS * 4, st, gg, tab, nfg, std::max(1, rmax), qa.as<int>(), ra.as<int>(), sy);
+        } else if (lds_tables) {
           const size_t lb = (size_t)W_IMAGE_WORDS * 4 + (size_t)cn_waves * std::max(1, rmax) * 64 * 4;
           const size_t want = ((size_t)m * nfg + cn_waves - 1) / cn_waves;
           hipLaunchKernelGGL(cn_lds_kern, dim3((unsigned)std::min<size_t>(want, (size_t)num_cu)), dim3(cn_waves * 64),
@@ -945,7 +1127,12 @@ struct GfEngine : Engine {
       prof_end(st);
       prof_begin(K_VN, st);
       if constexpr (WHT) {
-        if (lds_tables) {
+        if (lds_tables && vn_q_kern && (size_t)std::max(m, n) * nfg < (1u << 31)) {
+          const size_t want = ((size_t)n * nfg + 15) / 16;
+          hipLaunchKernelGGL(vn_q_kern, dim3((unsigned)std::min<size_t>(want, (size_t)2 * num_cu)), dim3(1024),
+                             (size_t)W_IMAGE_WORDS * 4, st, gg, tab, nfg, fna.as<int>(), ra.as<int>(), qa.as<int>(),
+                             xhat.as<uint8_t>(), fs.frozen);
+        } else if (lds_tables) {
           const size_t want = ((size_t)n * nfg + 15) / 16;
           hipLaunchKernelGGL(vn_lds_kern, dim3((unsigned)std::min<size_t>(want, (size_t)num_cu)), dim3(1024),
                              (size_t)W_IMAGE_WORDS * 4, st, gg, tab, nfg, fna.as<int>(), ra.as<int>(), qa.as<int>(),
