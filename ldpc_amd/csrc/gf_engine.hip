@@ -400,11 +400,14 @@ __device__ __forceinline__ int w_fexp_q(const uint32_t *img, int x) {
   x = x > W_LEVELS - 1 ? W_LEVELS - 1 : x;
   const int e = x >> W_DECI, fr = x & (kWhtFrac - 1);
   const int sh = 18 - e;                                   // >= 1 unless x > 17 * kWhtFrac
-  const int shc = sh < 1 ? 1 : sh;
-  const unsigned long long Y = (1ull << 32) | img[W_IMG_XEXP + fr];
-  const unsigned v = (unsigned)((Y + (1ull << ((shc - 1) & 63))) >> (shc & 63));
+  // (Y + 2^(sh-1)) >> sh with Y = 2^32 + mantissa, in 32-bit steps: t = Y >> (sh - 1) =
+  // (2^31 + mantissa / 2) >> (sh - 2), result (t + 1) >> 1; sh < 2 only at or above 17 * kWhtFrac,
+  // where the result is 2^31 either way
+  const unsigned y1 = __builtin_amdgcn_alignbit(1u, img[W_IMG_XEXP + fr], 1);
+  const unsigned t = y1 >> ((sh - 2) & 31);
+  const unsigned v = (t >> 1) + (t & 1u);
   const int r = sh >= 34 ? 0 : (int)v;
-  return x > 17 * kWhtFrac ? (int)(1u << 31) : r;
+  return x >= 17 * kWhtFrac ? (int)(1u << 31) : r;
 }
 __device__ __forceinline__ int w_flog_q(const uint32_t *img, const WTab &t, const int x) {
   const int xs = x < 1 ? 1 : x;
@@ -427,13 +430,30 @@ __device__ __forceinline__ int w_flog_q(const uint32_t *img, const WTab &t, cons
   v += i << W_DECI;
   return x <= 0 ? -W_FMUL * 14 : v;
 }
+// the value of lane l ^ (1 << B), B = 0..2, by DPP moves (no trip through the LDS crossbar and no
+// wait for it, which is what __shfl_xor compiles to): quad permutes for 1 and 2, for 4 the two row
+// shifts by four lanes, of which a lane takes the one that stays inside its group of eight
+template <int B>
+__device__ __forceinline__ int xor_lane(const int y, const int a) {
+  if (B == 0) return __builtin_amdgcn_update_dpp(0, y, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+  if (B == 1) return __builtin_amdgcn_update_dpp(0, y, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true);
+  const int up = __builtin_amdgcn_update_dpp(0, y, 0x104 /* row_shl:4: from lane l + 4 */, 0xf, 0xf, true);
+  const int dn = __builtin_amdgcn_update_dpp(0, y, 0x114 /* row_shr:4: from lane l - 4 */, 0xf, 0xf, true);
+  return (a & 4) ? dn : up;
+}
 template <int LQ>
 __device__ __forceinline__ int wht_q(int y, const int a) {
-#pragma unroll
-  for (int b = 0; b < LQ; b++) {
-    const int partner = __shfl_xor(y, 1 << b);
-    y = (a & (1 << b)) ? partner - y : y + partner;
-  }
+  static_assert(LQ >= 1 && LQ <= 3, "butterflies by DPP up to GF(8)");
+  { const int p = xor_lane<0>(y, a); y = (a & 1) ? p - y : y + p; }
+  if (LQ >= 2) { const int p = xor_lane<1>(y, a); y = (a & 2) ? p - y : y + p; }
+  if (LQ >= 3) { const int p = xor_lane<2>(y, a); y = (a & 4) ? p - y : y + p; }
+  return y;
+}
+template <int LQ>
+__device__ __forceinline__ int sum_q(int y, const int a) {
+  y += xor_lane<0>(y, a);
+  if (LQ >= 2) y += xor_lane<1>(y, a);
+  if (LQ >= 3) y += xor_lane<2>(y, a);
   return y;
 }
 // work items (node, frame group) of a persistent workgroup: wavefront w of block b starts at
@@ -536,9 +556,7 @@ __global__ __launch_bounds__(1024) void gf2p_vn_q_kernel(GGraph g, WTab tab, int
     for (int k = 0; k < PF; k++) {
       if (k >= dv) break;
       int q = logprod - pre[k];
-      int sum = w_fexp_q(w_lds, q);
-#pragma unroll
-      for (int b = 0; b < LQ; b++) sum += __shfl_xor(sum, 1 << b);
+      int sum = sum_q<LQ>(w_fexp_q(w_lds, q), a);
       if (sum <= 0) sum = Q;
       q -= w_flog_q(w_lds, tab, sum);
       (qa + (size_t)pe[k] * row)[lo] = q;
