@@ -66,6 +66,64 @@ def test_gf2p_wht_vs_oracle(hip, oracle, q, fname, F, p, it):
     assert any(r["rc"] == 0 for r in ref)
 
 
+def _random_nb_code(rng, q, m, n, row_w, col_cap, heavy=0):
+    """Random H[m][n] over GF(q): row weights drawn from row_w, no column above col_cap, no empty column;
+    `heavy` columns are then filled up to weight 5 (rows stay within row_w[1] + 1)."""
+    H = np.zeros((m, n), np.int32)
+    colw = np.zeros(n, np.int32)
+    for j in range(m):
+        w = int(rng.integers(row_w[0], row_w[1] + 1))
+        free = np.flatnonzero(colw < col_cap)
+        pick = rng.choice(free, size=w, replace=False)
+        H[j, pick] = rng.integers(1, q, size=w)
+        colw[pick] += 1
+    for v in np.flatnonzero(colw == 0):          # every symbol is checked, by a row that has room
+        roww = np.count_nonzero(H, axis=1)
+        H[int(rng.choice(np.flatnonzero(roww < row_w[1]))), v] = int(rng.integers(1, q))
+    for v in rng.choice(n, size=heavy, replace=False):
+        while np.count_nonzero(H[:, v]) < 5:
+            roww = np.count_nonzero(H, axis=1)
+            H[int(rng.choice(np.flatnonzero((roww <= row_w[1]) & (H[:, v] == 0)))), v] = int(rng.integers(1, q))
+    return H
+
+
+@pytest.mark.parametrize("q,m,n,row_w,col_cap,heavy,p,mode", [
+    (4, 150, 400, (5, 8), 3, 0, 0.01, "1"),      # GF(4), row weights 5..8: the PF = 8 build of the specialised check kernel
+    (8, 120, 320, (5, 8), 3, 0, 0.01, "1"),      # GF(8), the same
+    (4, 150, 400, (5, 7), 3, 4, 0.03, "1"),      # four columns of weight 5: the PF = 8 build of the variable kernel
+    (8, 120, 320, (5, 7), 3, 4, 0.03, "1"),
+    (4, 90, 150, (3, 4), 4, 0, 0.012, "2"),      # the generic LDS-table kernels on a GF(4) code
+    (16, 60, 100, (3, 5), 4, 0, 0.05, "1"),      # GF(16): not specialised, generic LDS-table kernels
+    (4, 100, 420, (9, 10), 3, 0, 0.005, "1"),    # row weight beyond 8: generic LDS-table kernels
+])
+def test_gf2p_wht_random_codes(hip, oracle, tmp_path, monkeypatch, q, m, n, row_w, col_cap, heavy, p, mode):
+    """Every build of the GF(2^p) kernels against the oracle of GFq_LDPC_NTT.c:437-544 on small random
+    codes (the reference's two codes only reach the weight <= 4 builds): decoded symbols, iteration
+    counts, verdicts and syndromes, bit-exact."""
+    rng = np.random.default_rng(q * 1000 + m)
+    H = _random_nb_code(rng, q, m, n, row_w, col_cap, heavy)
+    path = str(tmp_path / "nb.alist")
+    hip.alist.matrix_to_alist_NB(H, path, q)
+    oc = oracle.load(path)
+    log2q = int(np.log2(q))
+    F, it = 37, 12
+    x, s, logfna, logp = _wht_frames(oracle, oc, q, F, p, 5)
+    ref = [oracle.dec_gf2p_wht(oc, log2q, logfna[f], s[f], it) for f in range(F)]
+    # rc = -2: a message left the range of the reference's unchecked Fexp table (undefined behaviour
+    # there, GFq_LDPC_NTT.c:236; the library clamps the index) -- such frames have no reference result
+    ok = np.array([r["rc"] in (0, -1) for r in ref])
+    assert ok.sum() >= F // 2 and len(set(r["iters"] for r in ref if r["rc"] != -2)) >= 2
+    assert any(r["rc"] == -1 for r in ref)
+    monkeypatch.setenv("LDPC_HIP_GF_LDS_TABLES", mode)
+    code = hip.Code.from_alist(path)
+    dec = hip.Decoder(code, hip.ALG.GF2P_WHT, max_frames=64)
+    out = dec.decode(logfna.astype(np.int32), s.astype(np.uint8), it)
+    assert np.array_equal(out["status"][ok], np.array([0 if r["rc"] == 0 else 1 for r in ref])[ok])
+    assert np.array_equal(out["iters"][ok], np.array([r["iters"] for r in ref])[ok])
+    assert np.array_equal(out["bits"][ok], np.stack([r["x"] for r in ref])[ok])
+    assert np.array_equal(out["synd"][ok], np.stack([r["z"] for r in ref])[ok])
+
+
 def _conf_matrix(q, perr):
     """Symmetric +-1 confusion matrix in the shape test_mex_NB_p.m:35-47 builds
     ([rec][sent], one read)."""
