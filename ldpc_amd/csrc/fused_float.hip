@@ -58,6 +58,7 @@ struct FfArgs {
   int32_t *status;         // [nframes] or null
   float *llr_out;          // [nframes][n] or null
   int *counter;            // frame queue head (zeroed by the host before the launch)
+  int chunk;               // frames a workgroup takes from the queue per atomic (>= 1), as in fused_kernels.hip.h
   // register-cached kernel only
   const uint16_t *vtabT;   // [VPT*CM][block]  (check << 5) | shift of its sign bit, per (thread, variable, edge)
   const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
@@ -135,15 +136,20 @@ __global__ __launch_bounds__(1024) void fused_ms_kernel(FfArgs a) {
 #pragma unroll
     for (int w = 0; w < NW; w++) sgL[SGW * a.m + w] = 1u;
     if (QG) argL[a.m] = 1; else sgL[SGW * a.m + NW] = 1u;
-    *frame_slot = atomicAdd(a.counter, 1);
   }
+  int q_next = 0, q_lim = 0;                    // (thread 0) the rest of the chunk of frames in hand
+  auto take_frame = [&]() {
+    if (q_next == q_lim) { q_next = atomicAdd(a.counter, a.chunk); q_lim = q_next + a.chunk; }
+    return q_next++;
+  };
+  if (tid == 0) *frame_slot = take_frame();
   __syncthreads();
 
   for (;;) {
     const int frame = *frame_slot;
     if (frame >= a.nframes) break;
     int next_frame = 0;
-    if (tid == 0) next_frame = atomicAdd(a.counter, 1);   // its round trip hides under the decoding
+    if (tid == 0) next_frame = take_frame();              // its round trip hides under the decoding
     {
       const size_t base = (size_t)frame * a.n;
       if (a.dt == 1) {
@@ -415,14 +421,19 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
   if (tid == 0) {
     ff_u4 none; none.x = 0u; none.y = 0u; none.z = 0xffffffffu; none.w = 0xffffffffu;   // message -0.0
     rec[a.m] = none;
-    *frame_slot = atomicAdd(a.counter, 1);
   }
+  int q_next = 0, q_lim = 0;                    // (thread 0) the rest of the chunk of frames in hand
+  auto take_frame = [&]() {
+    if (q_next == q_lim) { q_next = atomicAdd(a.counter, a.chunk); q_lim = q_next + a.chunk; }
+    return q_next++;
+  };
+  if (tid == 0) *frame_slot = take_frame();
   __syncthreads();
   for (;;) {
     const int frame = *frame_slot;
     if (frame >= a.nframes) break;
     int next_frame = 0;
-    if (tid == 0) next_frame = atomicAdd(a.counter, 1);
+    if (tid == 0) next_frame = take_frame();
     {
       const size_t base = (size_t)frame * a.n;
       if (a.dt == 1 && vec_in) {
@@ -905,6 +916,8 @@ struct FusedFloatEngine : Engine {
     a.maskT = d_maskT.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
+    a.chunk = (int)std::max<long>(1, std::min<long>(std::min<long>(4096 / n, nframes / (grid * 16)), 16));
+    if (const char *e = getenv("LDPC_HIP_FUSED_CHUNK")) a.chunk = std::max(1, atoi(e));
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
     LAUNCHCHK("fused_ms_kernel");

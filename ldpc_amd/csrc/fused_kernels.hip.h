@@ -53,6 +53,7 @@ struct FusedArgs {
   int32_t *status;        // [nframes] or null
   float *llr_out;         // [nframes][n] or null
   int *counter;           // frame queue head (zeroed by the host before the launch)
+  int chunk;              // frames a workgroup takes from the queue per atomic (>= 1; register-cached kernel)
   // register-cached kernel only (lds_schedule.cpp): colT/dcT are then [rounds][RM][block]
   // LDS words (pads already point at dummy words)
   const uint16_t *pos;    // [n] variable -> LDS word
@@ -464,7 +465,14 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
 #if LDPC_FUSED_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  if (tid == 0) *frame_slot = atomicAdd(a.counter, 1);
+  // Frames come from one device-wide counter, a.chunk at a time: short frames ((204,102): 80 million
+  // a second) would otherwise queue up on that one L2 address
+  int q_next = 0, q_lim = 0;                    // (thread 0) the rest of the chunk in hand
+  auto take_frame = [&]() {
+    if (q_next == q_lim) { q_next = atomicAdd(a.counter, a.chunk); q_lim = q_next + a.chunk; }
+    return q_next++;
+  };
+  if (tid == 0) *frame_slot = take_frame();
   __syncthreads();
   for (;;) {
     const int frame = *frame_slot;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(LB, MINW) void fused_q88_reg_kernel(FusedArgs a) {
     // the next frame's number is fetched now and published at the end of this frame: the
     // round trip of the device atomic hides under the decoding
     int next_frame = 0;
-    if (tid == 0) next_frame = atomicAdd(a.counter, 1);
+    if (tid == 0) next_frame = take_frame();
     {
       const size_t base = (size_t)frame * a.n;
       auto put = [&](int word, int v) { fsum[word] = FQ_BIAS + v; };   // one variable's q0 (on the Q8.8 grid, within int16)

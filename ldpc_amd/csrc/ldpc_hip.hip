@@ -865,6 +865,10 @@ struct FusedQ88Engine : Engine {
     }
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
+    // short frames are taken from the queue several at a time (one atomic per chunk), while every
+    // workgroup still makes at least 16 trips so that the tail stays short
+    a.chunk = (int)std::max<long>(1, std::min<long>(std::min<long>(4096 / n, nframes / (grid * 16)), 16));
+    if (const char *e = getenv("LDPC_HIP_FUSED_CHUNK")) a.chunk = std::max(1, atoi(e));
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
     LAUNCHCHK("fused_q88_kernel");
