@@ -651,7 +651,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
   X(2, 16, 16, 3, 1024, 4) /* peg_16000_3_0.9 */ \
   X(2, 9, 10, 3, 512, 4)   /* 4095.737.3: two workgroups per CU */ \
   X(1, 7, 6, 3, 256, 4)    /* 1057.244.3: four */ \
-  X(1, 3, 2, 3, 128, 4)    /* 204.33.484: eight */
+  X(1, 3, 2, 3, 128, 4)    /* 204.33.484: eight */ \
+  X(1, 5, 2, 7, 1024, 4)   /* Frolov_1024_0.5 (the Verilog trace's code): irregular, column weights to 7 */
 
 namespace {
 
@@ -754,6 +755,9 @@ struct FusedFloatEngine : Engine {
         int vpt = (sc.var_words + B - 1) / B;
         if ((cmax & 1) && (vpt & 1)) vpt++;
         FfKern k = ff_reg_lookup(sc.rounds, RM / 2, vpt, cmax, B);
+        if (getenv("LDPC_HIP_DEBUG"))
+          fprintf(stderr, "fused float: shape {%d checks/thread, %d slot pairs, %d variables/thread, %d edges/variable, %d threads}: %s\n",
+                  sc.rounds, RM / 2, vpt, cmax, B, k ? "built" : "no register-cached kernel");
         if (!k) continue;
         hipFuncAttributes fa;
         HIPCHK(hipFuncGetAttributes(&fa, (const void *)k));
