@@ -149,6 +149,34 @@ using namespace ldpc;
 
 constexpr int EV_RING = 4;
 
+// ---- second stage of a two-stage decode (BinaryEngine::decode): the frames that have not met their
+// syndrome when the first stage stops are listed, their inputs gathered into a dense batch, and
+// their results written back over the first stage's
+__global__ void list_open_frames_kernel(int nframes, int V, const uint8_t *done, int *count, int *idx) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  if (!((done[f / V] >> (f % V)) & 1)) idx[atomicAdd(count, 1)] = f;
+}
+// rows of `row` bytes: dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter); one workgroup per row
+template <typename U, bool SCATTER>
+__global__ void move_rows_kernel(const U *__restrict__ src, U *__restrict__ dst, const int *__restrict__ idx, size_t row) {
+  const size_t i = blockIdx.x, f = (size_t)idx[blockIdx.x];
+  const U *s = src + (SCATTER ? i : f) * row;
+  U *d = dst + (SCATTER ? f : i) * row;
+  for (size_t k = threadIdx.x; k < row; k += blockDim.x) d[k] = s[k];
+}
+template <bool SCATTER>
+static void move_rows(const void *src, void *dst, const int *idx, int count, size_t row_bytes, hipStream_t st) {
+  if (count <= 0 || !src || !dst) return;
+  const bool w4 = row_bytes % 4 == 0 && ((size_t)src | (size_t)dst) % 4 == 0;
+  if (w4)
+    hipLaunchKernelGGL((move_rows_kernel<uint32_t, SCATTER>), dim3((unsigned)count), dim3(256), 0, st, (const uint32_t *)src,
+                       (uint32_t *)dst, idx, row_bytes / 4);
+  else
+    hipLaunchKernelGGL((move_rows_kernel<uint8_t, SCATTER>), dim3((unsigned)count), dim3(256), 0, st, (const uint8_t *)src,
+                       (uint8_t *)dst, idx, row_bytes);
+}
+
 template <typename T, int ALG>
 struct BinaryEngine : Engine {
   typedef typename MT<T>::vec vec;
@@ -164,6 +192,9 @@ struct BinaryEngine : Engine {
   DevBuf g_row_ptr, g_col_idx, g_col_ptr, g_edge_of, trace_buf;
   std::vector<int32_t> h_row_ptr, h_col_idx, h_col_ptr, h_edge_of;   // host copy (trace ordering)
   DevBuf q0, msg, post, hard, synd, sout, fail, done, iters, remaining, tab_lt, tab_g;
+  // two-stage decode: list of open frames (+ count), their gathered inputs and their results
+  DevBuf s2_idx, s2_llr, s2_synd, s2_bits, s2_iters, s2_sout, s2_status, s2_post;
+  bool one_stage_only = false;   // set by the allocation-free entry (the second stage allocates its batch)
   int32_t *h_remaining = nullptr;
   int remaining_cap = 0;
   hipEvent_t ev[EV_RING] = {};
@@ -367,9 +398,69 @@ struct BinaryEngine : Engine {
     return LDPC_OK;
   }
 
+  // Two stages when frames may leave early (opts.early_exit) and the batch is large: the slab layout
+  // keeps every frame of a batch in the passes until the last one is done, so a batch in which 95 %
+  // of the frames converge in 15 iterations and the rest need 50 costs 50 iterations for all.  The
+  // first stage therefore stops once at most 1/16 of the frames are still open (and at least 8
+  // iterations remain); the open frames are decoded again, from their channel values, as a dense
+  // batch of their own.  dec() is deterministic, so a frame's bits, iteration count, syndrome and
+  // verdict are the ones one stage gives (LDPC_HIP_TWO_STAGE=0 turns the second stage off).
   int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
              int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
              hipStream_t st) override {
+    const char *ts_env = getenv("LDPC_HIP_TWO_STAGE");
+    const bool two_stage_env = !ts_env || atoi(ts_env) != 0;
+    const bool two = two_stage_env && !one_stage_only && opts.early_exit != 0 && nframes >= 8 * SF && max_iter >= 16 &&
+                     dt >= 0 && dt <= 3;
+    if (!two) return decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, 0, nullptr);
+    bool stopped = false;
+    int rc = decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, nframes / 16, &stopped);
+    if (rc || !stopped) return rc;
+    const int stage1_iterations = last_iterations;
+    // the open frames, in whatever order the lanes report them
+    if ((rc = s2_idx.ensure(sizeof(int) * ((size_t)nframes / 16 + 64)))) return rc;
+    int *d_count = s2_idx.as<int>(), *d_idx = s2_idx.as<int>() + 32;
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(int), st));
+    hipLaunchKernelGGL(list_open_frames_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, nframes, V,
+                       done.as<uint8_t>(), d_count, d_idx);
+    LAUNCHCHK("list_open_frames_kernel");
+    int count = 0;
+    HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (count <= 0) return LDPC_OK;
+    if (count > nframes / 16) { ldpc_set_error("two-stage decode: more open frames than the first stage reported"); return LDPC_ERR_HIP; }
+    static const size_t elt[4] = {8, 4, 2, 4};
+    const size_t in_row = (size_t)n * elt[dt];
+    if ((rc = s2_llr.ensure(in_row * count))) return rc;
+    if (sy_in && (rc = s2_synd.ensure((size_t)m * count))) return rc;
+    if (bits && (rc = s2_bits.ensure((size_t)n * count))) return rc;
+    if (iters_out && (rc = s2_iters.ensure(sizeof(int32_t) * count))) return rc;
+    if (sout_out && (rc = s2_sout.ensure((size_t)m * count))) return rc;
+    if (status && (rc = s2_status.ensure(sizeof(int32_t) * count))) return rc;
+    if (llr_out && (rc = s2_post.ensure(sizeof(float) * (size_t)n * count))) return rc;
+    move_rows<false>(llr, s2_llr.p, d_idx, count, in_row, st);
+    if (sy_in) move_rows<false>(sy_in, s2_synd.p, d_idx, count, (size_t)m, st);
+    LAUNCHCHK("move_rows_kernel (gather)");
+    rc = decode_once(count, s2_llr.p, dt, sy_in ? s2_synd.as<uint8_t>() : nullptr, max_iter, bits ? s2_bits.as<uint8_t>() : nullptr,
+                     iters_out ? s2_iters.as<int32_t>() : nullptr, sout_out ? s2_sout.as<uint8_t>() : nullptr,
+                     status ? s2_status.as<int32_t>() : nullptr, llr_out ? s2_post.as<float>() : nullptr, st, 0, nullptr);
+    if (rc) return rc;
+    // d_idx lives in s2_idx, which decode_once does not touch
+    if (bits) move_rows<true>(s2_bits.p, bits, d_idx, count, (size_t)n, st);
+    if (iters_out) move_rows<true>(s2_iters.p, iters_out, d_idx, count, sizeof(int32_t), st);
+    if (sout_out) move_rows<true>(s2_sout.p, sout_out, d_idx, count, (size_t)m, st);
+    if (status) move_rows<true>(s2_status.p, status, d_idx, count, sizeof(int32_t), st);
+    if (llr_out) move_rows<true>(s2_post.p, llr_out, d_idx, count, sizeof(float) * (size_t)n, st);
+    LAUNCHCHK("move_rows_kernel (scatter)");
+    last_iterations = std::max(last_iterations, stage1_iterations);
+    return LDPC_OK;
+  }
+
+  // stop_open > 0: leave the iteration loop once at most stop_open frames are still open, provided
+  // at least 8 iterations remain (*stopped tells); those frames come out as "not converged"
+  int decode_once(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+                  int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+                  hipStream_t st, int stop_open, bool *stopped) {
     if (nframes <= 0) return LDPC_OK;
     if (nframes > nslab_max * SF || !llr || max_iter < 0 || max_iter > 65000) {
       ldpc_set_error("nframes/max_iter out of range for this decoder");
@@ -421,6 +512,13 @@ struct BinaryEngine : Engine {
         if (t >= 2) {
           HIPCHK(hipEventSynchronize(ev[(t - 2) % EV_RING]));
           if (h_remaining[t - 2] == 0) { all_done = true; break; }
+          if (stop_open > 0 && h_remaining[t - 2] <= stop_open && max_iter - t >= 8) {
+            // (the open frames' decisions of iteration t - 1 have been tested and stay as they are:
+            // no closing variable pass, as when every frame is done)
+            all_done = true;
+            *stopped = true;
+            break;
+          }
         }
       }
     }
@@ -491,7 +589,10 @@ struct BinaryEngine : Engine {
         b4(synd, w + off[WS_SYND], len[WS_SYND]), b5(sout, w + off[WS_SOUT], len[WS_SOUT]),
         b6(fail, w + off[WS_FAIL], len[WS_FAIL]), b7(done, w + off[WS_DONE], len[WS_DONE]),
         b8(iters, w + off[WS_ITERS], len[WS_ITERS]), b9(remaining, w + off[WS_REM], len[WS_REM]);
-    return decode(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+    one_stage_only = true;
+    const int rc = decode(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+    one_stage_only = false;
+    return rc;
   }
 
   int emit_outputs(int nframes, int nslab, int max_iter, uint8_t *bits, int32_t *iters_out,

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 from conftest import code_path, make_frames, to_q88
+from test_gpu_binary import check_exact, run_oracle
+from test_zz_no_alloc import _run as _run_on_device
 
 pytestmark = pytest.mark.gpu
 NAME = "204.33.484.txt"
@@ -123,3 +125,42 @@ def test_gf_no_frames_and_zero_iterations(hip, oracle):
     assert np.array_equal(out["iters"], np.array([r["iters"] for r in ref]))
     full = dec.decode(lf, s, int(g["maxit"]))
     assert np.array_equal(full["bits"], g["xhat"]) and np.array_equal(full["status"] != 0, g["rc"] != 0)
+
+
+@pytest.mark.parametrize("alg", ["MINSUM_Q88", "SPA_F32", "MINSUM_F64"])
+def test_two_stage_decode_equals_one_stage(hip, oracle, monkeypatch, alg):
+    """Two-pass engine, early exit, a batch large enough for the two-stage schedule (BinaryEngine::decode):
+    the first stage stops once at most 1/16 of the frames are open, those are decoded again as a dense
+    batch.  Every output must equal the one-stage decode's, and (Q8.8) the oracle's."""
+    name, F, it = "204.33.484.txt", 4500, 40
+    oc = oracle.load(code_path(name))
+    x, s, llr = make_frames(oracle, oc, F, 0.0, 23, "awgn", sigma=0.72)
+    q, raw = to_q88(llr)
+    su = s.astype(np.uint8)
+    monkeypatch.setenv("LDPC_HIP_FUSED", "0")            # the two-pass engine for every algorithm
+    code = hip.Code.from_alist(code_path(name))
+    inp = raw if alg == "MINSUM_Q88" else (llr.astype(np.float32) if alg == "SPA_F32" else llr)
+    outs, launches = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LDPC_HIP_TWO_STAGE", mode)
+        dec = hip.Decoder(code, getattr(hip.ALG, alg), max_frames=F, early_exit=True, want_llr=True)
+        dec.profile(True)
+        outs[mode] = _run_on_device(hip, dec, code, inp, su, it, False, want_llr=True)   # (the host-buffer entry decodes in chunks)
+        _, cnt = dec.profile_read()
+        launches[mode] = int(cnt[1])
+        dec.close()
+    one, two = outs["0"], outs["1"]
+    open_frames = int((one["status"] != 0).sum())
+    slow = int((one["iters"] > 12).sum())
+    print(f"{alg}: {open_frames} frames fail, {slow} need more than 12 iterations; check passes launched: one stage {launches['0']}, two stages {launches['1']}")
+    assert 0 < open_frames <= F // 16, "pick a noise level at which a few frames fail"
+    # a failing frame keeps one stage going to the last iteration; two stages: a short first stage, then all of them again
+    assert launches["0"] == it and it < launches["1"] < 2 * it - 7
+    for key in ("status", "iters", "bits", "synd"):
+        assert np.array_equal(one[key], two[key]), key
+    assert np.array_equal(one["llr"], two["llr"], equal_nan=True)
+    if alg == "MINSUM_Q88":
+        pick = np.unique(np.concatenate([np.flatnonzero(one["iters"] > 6)[:80], np.arange(60)]))
+        ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q[pick], s[pick], it)
+        sub = {k: two[k][pick] for k in ("status", "iters", "bits", "synd")}
+        check_exact(sub, ref, "two-stage q88")
