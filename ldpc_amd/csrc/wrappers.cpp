@@ -76,12 +76,18 @@ struct Cached {
 };
 std::vector<Cached> g_cache;
 
-int mc_batch() {
+// Frames per device pass of the Monte-Carlo harnesses: LDPC_HIP_MC_BATCH, else about 4 GB of
+// 8-byte edge messages' worth, between 1024 and 16384 frames in steps of 512 (binary codes; a
+// non-binary message is q values: 1024) -- large enough that short codes fill the GPU and that the
+// two-pass decoders' two-stage early exit (BinaryEngine::decode) has a batch to work with.
+int mc_batch(const ldpc_code *c = nullptr) {
   if (const char *e = getenv("LDPC_HIP_MC_BATCH")) {
     int v = atoi(e);
     if (v > 0) return v;
   }
-  return 1024;
+  if (!c || ldpc_code_q(c) != 2) return 1024;
+  const long f = (long)(4.0e9 / (8.0 * std::max(1, ldpc_code_edges(c))));
+  return (int)std::min<long>(16384, std::max<long>(1024, f / 512 * 512));
 }
 
 int cache_device() {
@@ -112,7 +118,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
   memset(&o, 0, sizeof o);
   o.alg = alg;
   o.device = cache_device();
-  o.max_frames = mc_batch();
+  o.max_frames = mc_batch(c);
   o.early_exit = 1;
   ldpc_decoder *d = nullptr;
   rc = ldpc_decoder_create(c, &o, &d);
