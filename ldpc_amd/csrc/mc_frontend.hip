@@ -214,32 +214,45 @@ __global__ __launch_bounds__(256) void mc_gen_kernel(McArgs a) {
 
 // counters: 0 frames, 1 not converged, 2 converged to a word != x, 3 bit errors (all
 // frames), 4 iterations, 5 frames with any bit error, 6 bit errors of converged frames
+// One wavefront per frame at a time, many frames per workgroup, the counts carried in registers and
+// merged through LDS: seven device atomics per WORKGROUP.  (One workgroup and up to six device
+// atomics per FRAME, as this kernel first was, took 70 % of a (204,102) Monte-Carlo pass: every
+// frame of the batch queued on the same seven L2 addresses.)
 __global__ __launch_bounds__(256) void mc_classify_kernel(int n, int nframes, const uint8_t *x, const uint8_t *bits,
                                                           const int32_t *status, const int32_t *iters,
                                                           unsigned long long *counters) {
-  __shared__ int red[4];
-  const int f = blockIdx.x;
-  if (f >= nframes) return;
-  int diff = 0;
-  const uint8_t *xr = x + (size_t)f * n, *br = bits + (size_t)f * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) diff += (xr[i] ^ br[i]) & 1;
-  for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = diff;
+  __shared__ unsigned long long acc[8];
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += red[w];
-    const int st = status[f];
-    atomicAdd(&counters[0], 1ull);
-    if (st) atomicAdd(&counters[1], 1ull);
-    else if (tot) atomicAdd(&counters[2], 1ull);
-    if (tot) {
-      atomicAdd(&counters[3], (unsigned long long)tot);
-      atomicAdd(&counters[5], 1ull);
-      if (!st) atomicAdd(&counters[6], (unsigned long long)tot);
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned long long c[7] = {0, 0, 0, 0, 0, 0, 0};   // (the same in every lane of the wavefront)
+  for (int f = blockIdx.x * nw + wave; f < nframes; f += gridDim.x * nw) {
+    const uint8_t *xr = x + (size_t)f * n, *br = bits + (size_t)f * n;
+    int diff = 0;
+    if (((n & 3) | ((size_t)x & 3) | ((size_t)bits & 3)) == 0) {
+      const uint32_t *xw = (const uint32_t *)xr, *bw = (const uint32_t *)br;
+      for (int i = lane; i < (n >> 2); i += 64) diff += __popc((xw[i] ^ bw[i]) & 0x01010101u);
+    } else {
+      for (int i = lane; i < n; i += 64) diff += (xr[i] ^ br[i]) & 1;
     }
-    atomicAdd(&counters[4], (unsigned long long)iters[f]);
+    for (int o = 32; o > 0; o >>= 1) diff += __shfl_xor(diff, o);
+    const int st = status[f];
+    c[0] += 1ull;
+    if (st) c[1] += 1ull;
+    else if (diff) c[2] += 1ull;
+    if (diff) {
+      c[3] += (unsigned long long)diff;
+      c[5] += 1ull;
+      if (!st) c[6] += (unsigned long long)diff;
+    }
+    c[4] += (unsigned long long)iters[f];
   }
+  if (lane == 0)
+    for (int k = 0; k < 7; k++)
+      if (c[k]) atomicAdd(&acc[k], c[k]);
+  __syncthreads();
+  if (threadIdx.x < 7 && acc[threadIdx.x]) atomicAdd(&counters[threadIdx.x], acc[threadIdx.x]);
 }
 
 size_t dt_size(int dt) { return dt == LDPC_DT_F64 ? 8 : dt == LDPC_DT_I16 ? 2 : 4; }
@@ -417,7 +430,7 @@ extern "C" int ldpc_mc_run(ldpc_mc *mc, const ldpc_mc_opts *o, int64_t nframes, 
                                   mc->d_bits.as<uint8_t>(), mc->d_iters.as<int32_t>(), nullptr,
                                   mc->d_status.as<int32_t>(), nullptr, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(nf), dim3(256), 0, nullptr, n, nf, mc->d_x.as<uint8_t>(),
+    hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)std::min(2048, (nf + 3) / 4)), dim3(256), 0, nullptr, n, nf, mc->d_x.as<uint8_t>(),
                        mc->d_bits.as<uint8_t>(), mc->d_status.as<int32_t>(), mc->d_iters.as<int32_t>(),
                        mc->d_counters.as<unsigned long long>());
     LAUNCHCHK("mc_classify_kernel");
