@@ -776,23 +776,27 @@ __global__ __launch_bounds__(256) void gfq_vn_kernel(GGraph g, int nfg, const do
 // enc() (GFq_LDPC.c:299-310) of the current estimate and the distance to the
 // target syndrome: bit count for GF(2^p) (HamDist, GFq_LDPC_NTT.c:253-262),
 // symbol count otherwise.  One thread per (check, frame); frames across lanes.
+// a thread: one frame, `per` consecutive checks (up to 32, fewer when the launch would otherwise be
+// small) -- one atomic on the frame's distance per thread (one per unsatisfied check and frame
+// queued thousands deep on a frame's word when nothing converges)
 __global__ __launch_bounds__(256) void gf_synd_kernel(GGraph g, const uint8_t *__restrict__ xhat,
                                                       const uint8_t *__restrict__ synd,
                                                       uint8_t *__restrict__ zhat, int *__restrict__ dist,
-                                                      const uint8_t *__restrict__ frozen) {
-  const size_t total = (size_t)g.m * g.Fpad;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int f = (int)(idx % g.Fpad);
-  const int j = (int)(idx / g.Fpad);
-  if (frozen[f]) return;
-  int sum = 0;
-  for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++)
-    sum = gf_add(g, sum, g.mul[xhat[(size_t)g.col_idx[e] * g.Fpad + f] * g.Q + g.hval[e]]);
-  zhat[idx] = (uint8_t)sum;
-  const int z = synd ? synd[idx] : 0;
-  const int d = g.pow2 ? __popc((unsigned)(z ^ sum)) : (z != sum);
-  if (d) atomicAdd(&dist[f], d);
+                                                      const uint8_t *__restrict__ frozen, int per) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= g.Fpad || frozen[f]) return;
+  const int j0 = blockIdx.y * per, j1 = min(j0 + per, g.m);
+  int dsum = 0;
+  for (int j = j0; j < j1; j++) {
+    const size_t idx = (size_t)j * g.Fpad + f;
+    int sum = 0;
+    for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++)
+      sum = gf_add(g, sum, g.mul[xhat[(size_t)g.col_idx[e] * g.Fpad + f] * g.Q + g.hval[e]]);
+    zhat[idx] = (uint8_t)sum;
+    const int z = synd ? synd[idx] : 0;
+    dsum += g.pow2 ? __popc((unsigned)(z ^ sum)) : (z != sum);
+  }
+  if (dsum) atomicAdd(&dist[f], dsum);
 }
 
 struct FrameState {
@@ -1164,8 +1168,9 @@ struct GfEngine : Engine {
                            ra.as<double>(), qa.as<double>(), xhat.as<uint8_t>(), fs.frozen);
       LAUNCHCHK("gf vn kernel");
       prof_end(st);
-      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)(((size_t)m * Fpad + 255) / 256)), dim3(256), 0, st, gg,
-                         xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen);
+      const int synd_per = (int)std::max<size_t>(1, std::min<size_t>(32, (size_t)m * Fpad / (256 * 2048)));
+      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)((Fpad + 255) / 256), (unsigned)((m + synd_per - 1) / synd_per)), dim3(256), 0, st, gg,
+                         xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen, synd_per);
       LAUNCHCHK("gf_synd_kernel");
       hipLaunchKernelGGL(gf_state_kernel, dim3((Fpad + 255) / 256), dim3(256), 0, st, fs, Fpad, t, WHT ? 1 : 0,
                          remaining.as<int32_t>() + t);
