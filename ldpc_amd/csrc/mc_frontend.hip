@@ -146,7 +146,49 @@ __global__ __launch_bounds__(256) void mc_gen_kernel(McArgs a) {
   __syncthreads();
 
   // ---- x, LLRs (frame-major rows, coalesced)
-  for (int f = 0; f < nf; f++) {
+  // The two-valued channels (BSC) with int16 / binary32 outputs, rows of a multiple of 8 variables:
+  // eight variables per thread and step -- one byte of each bitmap, one 8-byte store of x, one
+  // 16- or 32-byte store of LLRs, the two possible values converted once.
+  const bool two_valued = a.channel == 0 || a.channel == 1;
+  const bool fast8 = two_valued && (a.n & 7) == 0 && (a.dt == LDPC_DT_I16 || a.dt == LDPC_DT_F32) &&
+                     ((size_t)a.x & 7) == 0 && ((size_t)a.llr & 15) == 0;
+  if (fast8) {
+    const int praw = q88_raw(a.llr_mag), nraw = q88_raw(-a.llr_mag);
+    const float pf = (float)a.llr_mag;
+    const int n8 = a.n >> 3;
+    for (int t = tid; t < nf * n8; t += B) {
+      const int f = t / n8, i8 = t - f * n8;
+      const uint32_t xbyte = (bm[(f * 2 + 0) * nw + (i8 >> 2)] >> ((i8 & 3) * 8)) & 0xffu;
+      const uint32_t ebyte = (bm[(f * 2 + 1) * nw + (i8 >> 2)] >> ((i8 & 3) * 8)) & 0xffu;
+      const uint32_t ybyte = xbyte ^ ebyte;
+      const size_t at = (size_t)(f0 + f) * a.n + (size_t)i8 * 8;
+      // bit k of the byte -> byte k of the word pair
+      uint2 xs;
+      xs.x = ((xbyte & 1u) | ((xbyte & 2u) << 7) | ((xbyte & 4u) << 14) | ((xbyte & 8u) << 21));
+      xs.y = (((xbyte >> 4) & 1u) | (((xbyte >> 4) & 2u) << 7) | (((xbyte >> 4) & 4u) << 14) | (((xbyte >> 4) & 8u) << 21));
+      *(uint2 *)(a.x + at) = xs;
+      if (a.dt == LDPC_DT_I16) {
+        uint4 v;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int lo = ((ybyte >> (2 * k)) & 1u) ? nraw : praw, hi = ((ybyte >> (2 * k + 1)) & 1u) ? nraw : praw;
+          w[k] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+        }
+        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        *(uint4 *)((int16_t *)a.llr + at) = v;
+      } else {
+        float4 v0, v1;
+        v0.x = (ybyte & 1u) ? -pf : pf;   v0.y = (ybyte & 2u) ? -pf : pf;
+        v0.z = (ybyte & 4u) ? -pf : pf;   v0.w = (ybyte & 8u) ? -pf : pf;
+        v1.x = (ybyte & 16u) ? -pf : pf;  v1.y = (ybyte & 32u) ? -pf : pf;
+        v1.z = (ybyte & 64u) ? -pf : pf;  v1.w = (ybyte & 128u) ? -pf : pf;
+        *(float4 *)((float *)a.llr + at) = v0;
+        *(float4 *)((float *)a.llr + at + 4) = v1;
+      }
+    }
+  }
+  for (int f = 0; f < (fast8 ? 0 : nf); f++) {
     const size_t row = (size_t)(f0 + f) * a.n;
     const uint32_t *xb = bm + (f * 2 + 0) * nw, *eb = bm + (f * 2 + 1) * nw;
     const uint64_t key = stream_key(a.seed, a.first_frame + (uint64_t)(f0 + f), 1);
@@ -350,7 +392,9 @@ static int mc_generate_pass(ldpc_mc *mc, const ldpc_mc_opts *o, uint64_t first, 
   a.row_ptr = mc->d_row_ptr.as<int32_t>(); a.col_idx = mc->d_col_idx.as<int32_t>();
   a.x = mc->d_x.as<uint8_t>(); a.llr = mc->d_llr.p; a.synd = mc->d_synd.as<uint8_t>();
   const size_t per_frame = (size_t)a.nw * 8;
-  int fpw = (int)((size_t)(96 * 1024) / per_frame);
+  // (about 32 KB of bitmaps per workgroup: several 256-thread workgroups per CU; 96 KB -- one
+  // workgroup, four wavefronts per CU -- left every phase of the kernel waiting on its own latencies)
+  int fpw = (int)((size_t)(32 * 1024) / per_frame);
   if (fpw > 32) fpw = 32;
   if (fpw < 1) fpw = 1;
   a.fpw = fpw;
