@@ -629,6 +629,137 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
   if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
 }
 
+// Table sum-product with both tables in LDS (engine.h: kTabc* has the format, tables.cpp builds and
+// checks the image).  The gathers of the other kernels go to 32 MiB of tables through the vector L1:
+// 64 requests per wavefront instruction, three instructions per edge and frame.  Here a workgroup
+// copies the 145 KiB image into LDS once and a table value costs two LDS reads and ~20 vector
+// instructions; log tanh of every input is looked up ONCE and kept (in the row's own registers with
+// the sign in bit 0 when the row weight is <= RB, else it is looked up again on the second sweep over
+// the rows).  Same sums, same differences, same table values: bit-exact (test_code_B.c:195-213).
+#define TABC_SPLIT 16384
+#define TABC_BLOCKS 10336
+#define TABC_END (TABC_SPLIT + 16 * TABC_BLOCKS)
+#define TABC_C0 159000
+#define TABC_M 11400
+#define TABC_ZERO (14 << 14)
+#define TABC_BYTES (2 * (TABC_SPLIT * 2 + TABC_BLOCKS * 4))
+
+// |table[i]|; i as unsigned, so a negative argument is "beyond the table" (0) like the reference's range tests
+__device__ __forceinline__ int tabc_mag(const uint16_t *ab, const uint32_t *cb, unsigned i) {
+  const unsigned ia = i < (unsigned)TABC_SPLIT ? i : (unsigned)TABC_SPLIT - 1u;
+  const int e = 31 - __clz((int)(ia | 1u));
+  int va = (int)ab[ia] + (TABC_C0 - TABC_M * e);
+  va = i == 0u ? TABC_ZERO : va;
+  unsigned j = i < (unsigned)TABC_SPLIT ? 0u : i - (unsigned)TABC_SPLIT;
+  j = j > 16u * TABC_BLOCKS - 1u ? 16u * TABC_BLOCKS - 1u : j;
+  const unsigned w = cb[j >> 4];
+  const int vc = (int)(w >> 16) - __popc(w & ((2u << (j & 15u)) - 1u));
+  int r = i < (unsigned)TABC_SPLIT ? va : vc;
+  r = i >= (unsigned)TABC_END ? 0 : r;
+  return r;
+}
+
+template <int RB, int NT>
+__global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
+    Graph g, int nslab, int wps, MT<int>::vec *__restrict__ msg, const uint8_t *__restrict__ hard,
+    const uint8_t *__restrict__ synd, uint32_t *__restrict__ fail, const uint32_t *__restrict__ image) {
+  typedef MT<int>::vec vec;
+  constexpr int V = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 *src = reinterpret_cast<const u4 *>(image);
+    u4 *dst = reinterpret_cast<u4 *>(lds_raw);
+    for (int t = threadIdx.x; t < TABC_BYTES / 16; t += NT) dst[t] = src[t];
+  }
+  __syncthreads();
+  const uint16_t *abL = reinterpret_cast<const uint16_t *>(lds_raw);
+  const uint16_t *abG = abL + TABC_SPLIT;
+  const uint32_t *cbL = reinterpret_cast<const uint32_t *>(lds_raw) + TABC_SPLIT;
+  const uint32_t *cbG = cbL + TABC_BLOCKS;
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;      // (after the only barrier)
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb, sg = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    int lp[V];                 // -logprod: the table values are <= 0, their magnitudes are summed
+#pragma unroll
+    for (int v = 0; v < V; v++) lp[v] = 0;
+    if constexpr (RB > 0) {
+      vec x[RB];
+#pragma unroll
+      for (int k = 0; k < RB; k++)
+        if (k < dc) {
+          x[k] = rows[(size_t)k * 64];
+          par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+        }
+      failacc |= par;
+#pragma unroll
+      for (int k = 0; k < RB; k++)
+        if (k < dc) {
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const int xv = x[k][v];
+            const unsigned neg = xv < 0 ? 1u : 0u;
+            const int l = tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
+            lp[v] += l;
+            x[k][v] = (int)(((unsigned)l << 1) | neg);
+            sg ^= neg << v;
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < RB; k++)
+        if (k < dc) {
+          vec o;
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const unsigned pk = (unsigned)x[k][v];
+            const int tout = tabc_mag(abG, cbG, (unsigned)(lp[v] - (int)(pk >> 1)));
+            const bool flip = (((sg >> v) ^ pk) & 1u) != 0;
+            o[v] = flip ? -tout : tout;
+          }
+          rows[(size_t)k * 64] = o;
+        }
+    } else {
+      for (int k = 0; k < dc; k++) {
+        const vec x = rows[(size_t)k * 64];
+        par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          const int xv = x[v];
+          const unsigned neg = xv < 0 ? 1u : 0u;
+          lp[v] += tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
+          sg ^= neg << v;
+        }
+      }
+      failacc |= par;
+      for (int k = 0; k < dc; k++) {
+        const vec x = rows[(size_t)k * 64];
+        vec o;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          const int xv = x[v];
+          const unsigned neg = xv < 0 ? 1u : 0u;
+          const int l = tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
+          const int tout = tabc_mag(abG, cbG, (unsigned)(lp[v] - l));
+          const bool flip = (((sg >> v) ^ neg) & 1u) != 0;
+          o[v] = flip ? -tout : tout;
+        }
+        rows[(size_t)k * 64] = o;
+      }
+    }
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
 // Closing syndrome pass: sout = H * hard (the reference's tmp_s) and
 // fail |= sout ^ target.  enc() + HamDist(), test_code_min_sum_B.c:200-203.
 __global__ __launch_bounds__(256) void synd_kernel(Graph g, int nslab,

@@ -159,6 +159,23 @@ void ldpc_build_wht_compact(WhtCompact &c);
 uint32_t ldpc_wht_fexp_compact(const WhtCompact &c, int x);
 int ldpc_wht_flog_compact(const WhtCompact &c, int i, bool *defer);
 long ldpc_wht_compact_selfcheck(long stats[4]);
+// compact exact form of the two Q8.14 sum-product tables (tables.cpp; kernels: binary_kernels.hip.h
+// cn_tab_lds_kernel).  Both tables are monotone, zero from entry 181 705 on, step by at most one per
+// entry from entry 16 384 on and stay within 16 bits of a line per octave below that:
+//   [0, 16384):      u16 ab[i] = |t[i]| - (kTabcC0 - kTabcM * floor(log2(i | 1)))   (entry 0 is a constant)
+//   [16384, kTabcEnd): u32 per 16 entries = |t| of the entry before the block << 16 | one bit per entry
+//                    that is one smaller than its predecessor
+// image: ab of Flogtanh, ab of Fgallag, blocks of Flogtanh, blocks of Fgallag = kTabcBytes (145 KiB, one
+// workgroup's LDS).
+constexpr int kTabcSplit = 16384;
+constexpr int kTabcBlocks = 10336;
+constexpr int kTabcEnd = kTabcSplit + 16 * kTabcBlocks;          // 181 760
+constexpr int kTabcC0 = 159000, kTabcM = 11400, kTabcZero = 14 << 14;
+constexpr int kTabcBytes = 2 * (kTabcSplit * 2 + kTabcBlocks * 4);   // 148 224
+bool ldpc_build_spa_compact(const std::vector<int32_t> &flogtanh, const std::vector<int32_t> &fgallag,
+                            std::vector<uint32_t> &image);
+int ldpc_spa_compact_mag(const uint32_t *image, int table, unsigned i);   // the kernels' arithmetic, restated
+long ldpc_spa_compact_selfcheck(long stats[4]);
 void ldpc_gf_tables_host(int q, int *logq, int *expq);
 int ldpc_gf_mul_host(int q, int a, int b);
 

@@ -183,6 +183,7 @@ struct BinaryEngine : Engine {
   static constexpr int V = MT<T>::V;
   static constexpr int SF = 64 * V;
 
+  static constexpr int TAB_NT = 512;   // threads per workgroup of cn_tab_lds_kernel (one workgroup per CU)
   ldpc_opts opts{};
   int n = 0, m = 0, E = 0, cmax = 0, rmax = 0;
   int nslab_max = 0;
@@ -191,7 +192,7 @@ struct BinaryEngine : Engine {
   int vn_bucket = 0;
   DevBuf g_row_ptr, g_col_idx, g_col_ptr, g_edge_of, trace_buf;
   std::vector<int32_t> h_row_ptr, h_col_idx, h_col_ptr, h_edge_of;   // host copy (trace ordering)
-  DevBuf q0, msg, post, hard, synd, sout, fail, done, iters, remaining, tab_lt, tab_g;
+  DevBuf q0, msg, post, hard, synd, sout, fail, done, iters, remaining, tab_lt, tab_g, tab_c;
   // two-stage decode: list of open frames (+ count), their gathered inputs and their results
   DevBuf s2_idx, s2_llr, s2_synd, s2_bits, s2_iters, s2_sout, s2_status, s2_post;
   bool one_stage_only = false;   // set by the allocation-free entry (the second stage allocates its batch)
@@ -264,9 +265,12 @@ struct BinaryEngine : Engine {
     // check-node kernel selection
     //   0 auto, 1 LDS staged through registers, 2 two-pass reload, 3 register
     //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA, 5 single read
-    //   with compressed per-frame state (min-sum, rmax <= 64)
+    //   with compressed per-frame state (min-sum, rmax <= 64), 6 both tables in LDS (table
+    //   sum-product; the default there, 4 when the tables do not have the structure it needs)
     cn_variant = o.cn_variant;
     if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) cn_variant = atoi(e);
+    const int cn_requested = cn_variant;
+    if (cn_variant == 6) cn_variant = 0;   // (chosen below, once the image is built)
     // measured on PEG-16000 (tools/bench_codes.py): the single-read kernel wins for min-sum
     // (+11 % over the reload kernel), the reload kernel for the float sum-product (+48 % over
     // the LDS-staged one), the DMA-staged one for the table sum-product
@@ -293,6 +297,21 @@ struct BinaryEngine : Engine {
       if ((rc = upload(tab_g, ga))) return rc;
       tab.flogtanh = tab_lt.as<int32_t>();
       tab.fgallag = tab_g.as<int32_t>();
+      // PEG-16000, 5 184 frames: 2.7 Gbit/s with the gathers (variant 4) -> see profiles/r02_bench_codes_table.txt
+      std::vector<uint32_t> image;
+      if ((cn_requested == 0 || cn_requested == 6) && ldpc_build_spa_compact(lt, ga, image)) {
+        static_assert(TABC_SPLIT == kTabcSplit && TABC_BLOCKS == kTabcBlocks && TABC_C0 == kTabcC0 &&
+                      TABC_M == kTabcM && TABC_ZERO == kTabcZero && TABC_BYTES == kTabcBytes, "image format");
+        if ((rc = tab_c.ensure(kTabcBytes))) return rc;
+        HIPCHK(hipMemcpy(tab_c.p, image.data(), kTabcBytes, hipMemcpyHostToDevice));
+        if constexpr (ALG == ALG_TAB) {
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<8, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<16, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<32, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<0, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+        }
+        cn_variant = 6;
+      }
     }
     return LDPC_OK;
   }
@@ -346,6 +365,25 @@ struct BinaryEngine : Engine {
         hipLaunchKernelGGL((cn_kernel<T, ALG, true>), grid, block, lds, st, g, nslab, msg.as<vec>(),
                            hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
       LAUNCHCHK("cn_kernel");
+      return LDPC_OK;
+    }
+    if (cn_variant == 6) {
+      // one workgroup per CU (its LDS holds the tables), TAB_NT / 64 waves each
+      if constexpr (ALG == ALG_TAB) {
+        const int wpb = TAB_NT / 64;
+        const int wps = balanced_wps(nslab, (long)num_cu * wpb * oversub);
+        const long waves = (long)wps * nslab;
+        dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(TAB_NT);
+#define TAB_LAUNCH(RB)                                                                                     \
+  hipLaunchKernelGGL((cn_tab_lds_kernel<RB, TAB_NT>), grid, block, kTabcBytes, st, g, nslab, wps, msg.as<vec>(), \
+                     hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab_c.as<uint32_t>())
+        if (rmax <= 8) TAB_LAUNCH(8);
+        else if (rmax <= 16) TAB_LAUNCH(16);
+        else if (rmax <= 32) TAB_LAUNCH(32);
+        else TAB_LAUNCH(0);
+#undef TAB_LAUNCH
+      }
+      LAUNCHCHK("cn_tab_lds_kernel");
       return LDPC_OK;
     }
     // 256-thread blocks, one wave per (check, slab) item

@@ -161,6 +161,82 @@ long ldpc_wht_compact_selfcheck(long stats[4]) {
   return bad_exp + bad_log;
 }
 
+// --- compact, exact form of the two Q8.14 sum-product tables (engine.h has the format) ---
+// The check pass of the table decoder gathers three table entries per edge and frame from 32 MiB of
+// tables: 64 separate L1 requests per wavefront instruction, which is what bounded it (2.7 Gbit/s on
+// PEG-16000 where the int32 min-sum pass, same traffic, is bandwidth-bound at 7.8).  The compact image
+// is built FROM the full tables (so whatever libm produced is what it holds) and refused when a table
+// does not have the structure the format needs; ldpc_spa_compact_selfcheck() replays the kernels'
+// arithmetic over all 2^22 arguments of both tables.
+bool ldpc_build_spa_compact(const std::vector<int32_t> &flogtanh, const std::vector<int32_t> &fgallag,
+                            std::vector<uint32_t> &image) {
+  const int levels = 1 << (8 + kDeci);
+  if ((int)flogtanh.size() != levels || (int)fgallag.size() != levels) return false;
+  image.assign(kTabcBytes / 4, 0);
+  uint16_t *ab[2] = {reinterpret_cast<uint16_t *>(image.data()),
+                     reinterpret_cast<uint16_t *>(image.data()) + kTabcSplit};
+  uint32_t *cb[2] = {image.data() + kTabcSplit, image.data() + kTabcSplit + kTabcBlocks};
+  for (int t = 0; t < 2; t++) {
+    const std::vector<int32_t> &src = t ? fgallag : flogtanh;
+    auto mag = [&](int i) { return t ? src[(size_t)i] : -src[(size_t)i]; };
+    if (mag(0) != kTabcZero) return false;
+    for (int i = 1; i < kTabcSplit; i++) {
+      int e = 0;
+      while ((i >> (e + 1)) != 0) e++;
+      const int r = mag(i) - (kTabcC0 - kTabcM * e);
+      if (r < 0 || r > 65535) return false;
+      ab[t][i] = (uint16_t)r;
+    }
+    for (int b = 0; b < kTabcBlocks; b++) {
+      const int i0 = kTabcSplit + 16 * b;
+      const int base = mag(i0 - 1);
+      if (base < 0 || base > 65535) return false;
+      uint32_t w = (uint32_t)base << 16;
+      for (int k = 0; k < 16; k++) {
+        const int step = mag(i0 + k - 1) - mag(i0 + k);
+        if (step != 0 && step != 1) return false;
+        w |= (uint32_t)step << k;
+      }
+      cb[t][b] = w;
+    }
+    for (int i = kTabcEnd - 1; i < levels; i++)
+      if (src[(size_t)i] != 0) return false;
+  }
+  return true;
+}
+
+int ldpc_spa_compact_mag(const uint32_t *image, int table, unsigned i) {
+  const uint16_t *ab = reinterpret_cast<const uint16_t *>(image) + (table ? kTabcSplit : 0);
+  const uint32_t *cb = image + kTabcSplit + (table ? kTabcBlocks : 0);
+  const unsigned ia = i < (unsigned)kTabcSplit ? i : (unsigned)kTabcSplit - 1;
+  int e = 0;
+  while (((ia | 1u) >> (e + 1)) != 0) e++;
+  int va = (int)ab[ia] + (kTabcC0 - kTabcM * e);
+  if (i == 0) va = kTabcZero;
+  unsigned j = i < (unsigned)kTabcSplit ? 0u : i - (unsigned)kTabcSplit;
+  if (j > 16u * kTabcBlocks - 1) j = 16u * kTabcBlocks - 1;
+  const uint32_t w = cb[j >> 4];
+  const int vc = (int)(w >> 16) - __builtin_popcount(w & ((2u << (j & 15u)) - 1u));
+  int r = i < (unsigned)kTabcSplit ? va : vc;
+  if (i >= (unsigned)kTabcEnd) r = 0;
+  return r;
+}
+
+long ldpc_spa_compact_selfcheck(long stats[4]) {
+  std::vector<int32_t> lt, ga;
+  ldpc_build_spa_tables(lt, ga);
+  std::vector<uint32_t> image;
+  const bool ok = ldpc_build_spa_compact(lt, ga, image);
+  long bad_l = 0, bad_g = 0;
+  if (ok)
+    for (unsigned i = 0; i < (unsigned)lt.size(); i++) {
+      if (-ldpc_spa_compact_mag(image.data(), 0, i) != lt[i]) bad_l++;
+      if (ldpc_spa_compact_mag(image.data(), 1, i) != ga[i]) bad_g++;
+    }
+  stats[0] = ok ? 1 : 0; stats[1] = bad_l; stats[2] = bad_g; stats[3] = kTabcBytes;
+  return ok ? bad_l + bad_g : -1;
+}
+
 // --- GF(q) ---
 // GF(2^p): discrete-log tables of the primitive polynomials whose powers are
 // the reference's expq literals (GFq_LDPC_NTT.c:25-92); prime q: mod q

@@ -258,6 +258,13 @@ extern "C" int64_t ldpc_wht_tables_selfcheck(int64_t *stats) {
   return bad;
 }
 
+extern "C" int64_t ldpc_spa_tables_selfcheck(int64_t *stats) {
+  long st[4] = {0, 0, 0, 0};
+  const long bad = ldpc_spa_compact_selfcheck(st);
+  if (stats) for (int i = 0; i < 4; i++) stats[i] = st[i];
+  return bad;
+}
+
 extern "C" void ldpc_set_seed(uint64_t seed) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_state = seed ? seed : clock_seed();

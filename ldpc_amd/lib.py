@@ -102,6 +102,8 @@ def load_library():
     L.ldpc_mc_set_qlc_channel.argtypes = [vp, vp, ip]
     L.ldpc_wht_tables_selfcheck.argtypes = [vp]
     L.ldpc_wht_tables_selfcheck.restype = C.c_int64
+    L.ldpc_spa_tables_selfcheck.argtypes = [vp]
+    L.ldpc_spa_tables_selfcheck.restype = C.c_int64
     L.ldpc_set_seed.argtypes = [C.c_uint64]
     L.ldpc_set_seed.restype = None
     dp, intp = C.POINTER(C.c_double), C.POINTER(C.c_int)

@@ -162,12 +162,13 @@ def test_spa_table(hip, oracle, name, F, p, sigma, it):
     check_exact(dec.decode(llr, s.astype(np.uint8), it), ref, f"tab {name} f64")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("name,F,p,it", [("204.33.484.txt", 200, 0.05, 15), ("peg_16000_3_0.9.txt", 9, 0.0015, 8),
                                          ("Frolov_1024_0.5.txt", 40, 0.045, 20)])
 def test_every_check_node_kernel_is_bit_exact(hip, oracle, name, F, p, it, variant):
     """The two-pass engine's check-node kernels (opts.cn_variant 1 LDS staged, 2 reload,
-    3 register resident, 4 DMA staged, 5 single read; 0 = the measured best per algorithm) all give the
+    3 register resident, 4 DMA staged, 5 single read, 6 both tables in LDS (table sum-product only; min-sum
+    then takes its default); 0 = the measured best per algorithm) all give the
     reference's results: Q8.8 (non-fused path), binary64 min-sum and the table sum-product."""
     oc = oracle.load(code_path(name))
     x, s, llr = make_frames(oracle, oc, F, p, 23, "bsc")
