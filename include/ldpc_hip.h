@@ -234,7 +234,7 @@ int ldpc_code_vpass_place_stats(const ldpc_code *c, int block, int64_t *stats);
 int64_t ldpc_wht_tables_selfcheck(int64_t *stats);
 
 /* The same for the binary table sum-product (no counterpart in the reference): its check pass reads
- * Flogtanh / Fgallag (inittab(), test_code_B.c:52-90) from a 145 KiB LDS image built from the two
+ * Flogtanh / Fgallag (inittab(), test_code_B.c:52-90) from a 153 KiB LDS image built from the two
  * 16 MiB tables; this replays the kernels' arithmetic on the host over all 2^22 arguments of both.
  * stats[4] = {1 if the tables had the structure the image needs (else the decoder gathers from the
  * full tables as before), Flogtanh entries that differ, Fgallag entries that differ, image bytes}.

@@ -632,34 +632,38 @@ __global__ __launch_bounds__(256) void cn_reg_kernel(
 // Table sum-product with both tables in LDS (engine.h: kTabc* has the format, tables.cpp builds and
 // checks the image).  The gathers of the other kernels go to 32 MiB of tables through the vector L1:
 // 64 requests per wavefront instruction, three instructions per edge and frame.  Here a workgroup
-// copies the 145 KiB image into LDS once and a table value costs two LDS reads and ~20 vector
-// instructions; log tanh of every input is looked up ONCE and kept (in the row's own registers with
-// the sign in bit 0 when the row weight is <= RB, else it is looked up again on the second sweep over
-// the rows).  Same sums, same differences, same table values: bit-exact (test_code_B.c:195-213).
+// copies the 153 KiB image into LDS once and a table value costs three LDS reads and ~18 vector
+// instructions.  Same sums, same differences, same table values: bit-exact (test_code_B.c:195-213).
+#define TABC_SMALL 2048
 #define TABC_SPLIT 16384
 #define TABC_BLOCKS 10336
-#define TABC_END (TABC_SPLIT + 16 * TABC_BLOCKS)
-#define TABC_C0 159000
-#define TABC_M 11400
-#define TABC_ZERO (14 << 14)
-#define TABC_BYTES (2 * (TABC_SPLIT * 2 + TABC_BLOCKS * 4))
+#define TABC_OFF_B 8208
+#define TABC_OFF_C (TABC_OFF_B + 28688)
+#define TABC_TABLE (TABC_OFF_C + TABC_BLOCKS * 4)
+#define TABC_BYTES (2 * TABC_TABLE)
 
-// |table[i]|; i as unsigned, so a negative argument is "beyond the table" (0) like the reference's range tests
-__device__ __forceinline__ int tabc_mag(const uint16_t *ab, const uint32_t *cb, unsigned i) {
-  const unsigned ia = i < (unsigned)TABC_SPLIT ? i : (unsigned)TABC_SPLIT - 1u;
-  const int e = 31 - __clz((int)(ia | 1u));
-  int va = (int)ab[ia] + (TABC_C0 - TABC_M * e);
-  va = i == 0u ? TABC_ZERO : va;
-  unsigned j = i < (unsigned)TABC_SPLIT ? 0u : i - (unsigned)TABC_SPLIT;
-  j = j > 16u * TABC_BLOCKS - 1u ? 16u * TABC_BLOCKS - 1u : j;
-  const unsigned w = cb[j >> 4];
-  const int vc = (int)(w >> 16) - __popc(w & ((2u << (j & 15u)) - 1u));
-  int r = i < (unsigned)TABC_SPLIT ? va : vc;
-  r = i >= (unsigned)TABC_END ? 0 : r;
-  return r;
+// |table[i]| from one table's image at t; i as unsigned, so a negative argument is "beyond the table"
+// (0) like the reference's range tests.  The three arrays are read at clamped indices and hold 0 where
+// they clamp, so the value is their sum: 15 vector instructions and 3 LDS reads, no branch, no select.
+__device__ __forceinline__ int tabc_mag(const unsigned char *t, unsigned i) {
+  const unsigned ia = i < (unsigned)TABC_SMALL ? i : (unsigned)TABC_SMALL;
+  unsigned ib = i > (unsigned)TABC_SMALL - 1u ? i : (unsigned)TABC_SMALL - 1u;
+  ib = ib < (unsigned)TABC_SPLIT ? ib : (unsigned)TABC_SPLIT;   // (v_med3_u32)
+  unsigned j = i - (unsigned)TABC_SPLIT;
+  j = j < 16u * TABC_BLOCKS - 1u ? j : 16u * TABC_BLOCKS - 1u;
+  const unsigned a = *reinterpret_cast<const uint32_t *>(t + 4u * ia);
+  const unsigned bq = *reinterpret_cast<const uint16_t *>(t + (TABC_OFF_B - 2 * (TABC_SMALL - 1)) + 2u * ib);
+  const unsigned w = *reinterpret_cast<const uint32_t *>(t + TABC_OFF_C + ((j >> 2) & ~3u));
+  return (int)(a + bq + (w >> 16)) - __popc(__builtin_amdgcn_ubfe(w, 0u, (j & 15u) + 1u));
 }
 
-template <int RB, int NT>
+// CH rows of a check are in registers at a time.  Everything is branch-free inside a chunk so that the
+// compiler can interleave the CH * 4 independent lookups (an LDS read is ~100 cycles away and one
+// workgroup per CU is all the tables leave room for): a slot beyond the row weight loads the check's
+// LAST row again, is masked out of the sums, and stores that row's (correct) output a second time.
+//   dc <= CH:  one chunk; log tanh of every input is looked up once and kept, with the sign in bit 31
+//   dc >  CH:  (CH <= 16 only) two sweeps over the rows in double-buffered chunks, rows read twice
+template <int CH, int NT>
 __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
     Graph g, int nslab, int wps, MT<int>::vec *__restrict__ msg, const uint8_t *__restrict__ hard,
     const uint8_t *__restrict__ synd, uint32_t *__restrict__ fail, const uint32_t *__restrict__ image) {
@@ -673,87 +677,113 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
     for (int t = threadIdx.x; t < TABC_BYTES / 16; t += NT) dst[t] = src[t];
   }
   __syncthreads();
-  const uint16_t *abL = reinterpret_cast<const uint16_t *>(lds_raw);
-  const uint16_t *abG = abL + TABC_SPLIT;
-  const uint32_t *cbL = reinterpret_cast<const uint32_t *>(lds_raw) + TABC_SPLIT;
-  const uint32_t *cbG = cbL + TABC_BLOCKS;
+  const unsigned char *tL = lds_raw, *tG = lds_raw + TABC_TABLE;
   const int lane = threadIdx.x & 63;
   const int w = wave_id_uniform();
   const int b = w % nslab;
   const int c0 = w / nslab;
   unsigned failacc = 0;
   if (c0 >= wps) return;      // (after the only barrier)
+  const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
   for (int j = c0; j < g.m; j += wps) {
     const int p0 = g.row_ptr[j];
     const int dc = g.row_ptr[j + 1] - p0;
     vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
     const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
-    unsigned par = sb, sg = sb;
-    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    unsigned par = sb;
+    if (dc <= 0) { failacc |= par; continue; }
     int lp[V];                 // -logprod: the table values are <= 0, their magnitudes are summed
+    int sg[V];                 // bit 31: s_j ^ XOR of the v2c signs (sgnprod, test_code_B.c:196-199)
 #pragma unroll
-    for (int v = 0; v < V; v++) lp[v] = 0;
-    if constexpr (RB > 0) {
-      vec x[RB];
+    for (int v = 0; v < V; v++) { lp[v] = 0; sg[v] = (int)(sb << (31 - v)); }
+
+    auto load = [&](int k0, vec (&x)[CH], unsigned (&hb)[CH], bool with_hard) {
 #pragma unroll
-      for (int k = 0; k < RB; k++)
-        if (k < dc) {
-          x[k] = rows[(size_t)k * 64];
-          par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
-        }
-      failacc |= par;
+      for (int c = 0; c < CH; c++) {
+        const int k = k0 + c < dc ? k0 + c : dc - 1;
+        x[c] = rows[(size_t)k * 64];
+        if (with_hard) hb[c] = hrow[(size_t)g.col_idx[p0 + k] * 64];
+      }
+    };
+    // first sweep over a chunk: sums and signs; PACK: the row's registers keep |log tanh| << 1 | sign
+    auto sweep1 = [&](int k0, vec (&x)[CH], unsigned (&hb)[CH], auto pack) {
 #pragma unroll
-      for (int k = 0; k < RB; k++)
-        if (k < dc) {
-#pragma unroll
-          for (int v = 0; v < V; v++) {
-            const int xv = x[k][v];
-            const unsigned neg = xv < 0 ? 1u : 0u;
-            const int l = tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
-            lp[v] += l;
-            x[k][v] = (int)(((unsigned)l << 1) | neg);
-            sg ^= neg << v;
-          }
-        }
-#pragma unroll
-      for (int k = 0; k < RB; k++)
-        if (k < dc) {
-          vec o;
-#pragma unroll
-          for (int v = 0; v < V; v++) {
-            const unsigned pk = (unsigned)x[k][v];
-            const int tout = tabc_mag(abG, cbG, (unsigned)(lp[v] - (int)(pk >> 1)));
-            const bool flip = (((sg >> v) ^ pk) & 1u) != 0;
-            o[v] = flip ? -tout : tout;
-          }
-          rows[(size_t)k * 64] = o;
-        }
-    } else {
-      for (int k = 0; k < dc; k++) {
-        const vec x = rows[(size_t)k * 64];
-        par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+      for (int c = 0; c < CH; c++) {
+        const unsigned m = k0 + c < dc ? ~0u : 0u;    // wave-uniform
+        par ^= hb[c] & m;
 #pragma unroll
         for (int v = 0; v < V; v++) {
-          const int xv = x[v];
-          const unsigned neg = xv < 0 ? 1u : 0u;
-          lp[v] += tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
-          sg ^= neg << v;
+          const int xv = x[c][v];
+          const int s = xv >> 31;
+          const int l = tabc_mag(tL, (unsigned)((xv ^ s) - s));
+          lp[v] += (int)((unsigned)l & m);
+          sg[v] ^= (int)((unsigned)xv & m);
+          if (decltype(pack)::value) x[c][v] = (int)(((unsigned)xv & 0x80000000u) | (unsigned)l);
         }
       }
+    };
+    auto store = [&](int k0, int c, vec o) {
+      const int k = k0 + c < dc ? k0 + c : dc - 1;
+      rows[(size_t)k * 64] = o;
+    };
+
+    if (dc <= CH) {
+      vec x[CH];
+      unsigned hb[CH];
+      load(0, x, hb, true);
+      sweep1(0, x, hb, std::true_type());
       failacc |= par;
-      for (int k = 0; k < dc; k++) {
-        const vec x = rows[(size_t)k * 64];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
         vec o;
 #pragma unroll
         for (int v = 0; v < V; v++) {
-          const int xv = x[v];
-          const unsigned neg = xv < 0 ? 1u : 0u;
-          const int l = tabc_mag(abL, cbL, (unsigned)(neg ? -xv : xv));
-          const int tout = tabc_mag(abG, cbG, (unsigned)(lp[v] - l));
-          const bool flip = (((sg >> v) ^ neg) & 1u) != 0;
-          o[v] = flip ? -tout : tout;
+          const int pk = x[c][v];
+          const int tout = tabc_mag(tG, (unsigned)(lp[v] - (pk & 0x7fffffff)));
+          const int s = (pk ^ sg[v]) >> 31;             // sgnprod != Sgntin[j][k]
+          o[v] = (tout ^ s) - s;
         }
-        rows[(size_t)k * 64] = o;
+        store(0, c, o);
+      }
+    } else if constexpr (CH <= 16) {
+      vec xa[CH], xb[CH];
+      unsigned ha[CH], hbb[CH];
+      load(0, xa, ha, true);
+      for (int k0 = 0; k0 < dc; k0 += 2 * CH) {
+        const bool second = k0 + CH < dc;
+        if (second) load(k0 + CH, xb, hbb, true);
+        sweep1(k0, xa, ha, std::false_type());
+        if (second) {
+          if (k0 + 2 * CH < dc) load(k0 + 2 * CH, xa, ha, true);
+          sweep1(k0 + CH, xb, hbb, std::false_type());
+        }
+      }
+      failacc |= par;
+      auto sweep2 = [&](int k0, vec (&x)[CH]) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          vec o;
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const int xv = x[c][v];
+            const int sx = xv >> 31;
+            const int l = tabc_mag(tL, (unsigned)((xv ^ sx) - sx));
+            const int tout = tabc_mag(tG, (unsigned)(lp[v] - l));
+            const int s = (xv ^ sg[v]) >> 31;
+            o[v] = (tout ^ s) - s;
+          }
+          store(k0, c, o);
+        }
+      };
+      load(0, xa, ha, false);
+      for (int k0 = 0; k0 < dc; k0 += 2 * CH) {
+        const bool second = k0 + CH < dc;
+        if (second) load(k0 + CH, xb, hbb, false);
+        sweep2(k0, xa);
+        if (second) {
+          if (k0 + 2 * CH < dc) load(k0 + 2 * CH, xa, ha, false);
+          sweep2(k0 + CH, xb);
+        }
       }
     }
   }

@@ -161,17 +161,22 @@ int ldpc_wht_flog_compact(const WhtCompact &c, int i, bool *defer);
 long ldpc_wht_compact_selfcheck(long stats[4]);
 // compact exact form of the two Q8.14 sum-product tables (tables.cpp; kernels: binary_kernels.hip.h
 // cn_tab_lds_kernel).  Both tables are monotone, zero from entry 181 705 on, step by at most one per
-// entry from entry 16 384 on and stay within 16 bits of a line per octave below that:
-//   [0, 16384):      u16 ab[i] = |t[i]| - (kTabcC0 - kTabcM * floor(log2(i | 1)))   (entry 0 is a constant)
-//   [16384, kTabcEnd): u32 per 16 entries = |t| of the entry before the block << 16 | one bit per entry
-//                    that is one smaller than its predecessor
-// image: ab of Flogtanh, ab of Fgallag, blocks of Flogtanh, blocks of Fgallag = kTabcBytes (145 KiB, one
-// workgroup's LDS).
+// entry from entry 16 384 on and fit 16 bits from entry 2 048 on.  Per table (kTabcTable bytes) three
+// arrays whose values ADD UP to |t[i]|: each is read at a clamped index and holds 0 where it clamps.
+//   u32 a[0..2048]:       |t[i]| below 2 048, a[2048] = 0
+//   u16 b[2047..16384]:   |t[i]| in [2 048, 16 384), b[2047] = b[16384] = 0
+//   u32 c[kTabcBlocks]:   from 16 384 on, per 16 entries: |t| of the entry before the block << 16 | one bit per
+//                         entry that is one smaller than its predecessor; the last entry (181 759) and all
+//                         beyond are 0, and arguments below 16 384 wrap to it
+// image: Flogtanh's three arrays, then Fgallag's = kTabcBytes (153 KiB, one workgroup's LDS).
+constexpr int kTabcSmall = 2048;
 constexpr int kTabcSplit = 16384;
 constexpr int kTabcBlocks = 10336;
 constexpr int kTabcEnd = kTabcSplit + 16 * kTabcBlocks;          // 181 760
-constexpr int kTabcC0 = 159000, kTabcM = 11400, kTabcZero = 14 << 14;
-constexpr int kTabcBytes = 2 * (kTabcSplit * 2 + kTabcBlocks * 4);   // 148 224
+constexpr int kTabcOffB = 8208;                                  // (2049 * 4, rounded up to 16)
+constexpr int kTabcOffC = kTabcOffB + 28688;                     // (14 338 * 2, rounded up to 16) = 36 896
+constexpr int kTabcTable = kTabcOffC + kTabcBlocks * 4;          // 78 240
+constexpr int kTabcBytes = 2 * kTabcTable;                       // 156 480
 bool ldpc_build_spa_compact(const std::vector<int32_t> &flogtanh, const std::vector<int32_t> &fgallag,
                             std::vector<uint32_t> &image);
 int ldpc_spa_compact_mag(const uint32_t *image, int table, unsigned i);   // the kernels' arithmetic, restated

@@ -183,7 +183,7 @@ struct BinaryEngine : Engine {
   static constexpr int V = MT<T>::V;
   static constexpr int SF = 64 * V;
 
-  static constexpr int TAB_NT = 512;   // threads per workgroup of cn_tab_lds_kernel (one workgroup per CU)
+  int tab_nt = 0, tab_rb = -1;   // cn_tab_lds_kernel: threads per workgroup (one workgroup per CU), rows in registers at a time (env overrides)
   ldpc_opts opts{};
   int n = 0, m = 0, E = 0, cmax = 0, rmax = 0;
   int nslab_max = 0;
@@ -300,15 +300,21 @@ struct BinaryEngine : Engine {
       // PEG-16000, 5 184 frames: 2.7 Gbit/s with the gathers (variant 4) -> see profiles/r02_bench_codes_table.txt
       std::vector<uint32_t> image;
       if ((cn_requested == 0 || cn_requested == 6) && ldpc_build_spa_compact(lt, ga, image)) {
-        static_assert(TABC_SPLIT == kTabcSplit && TABC_BLOCKS == kTabcBlocks && TABC_C0 == kTabcC0 &&
-                      TABC_M == kTabcM && TABC_ZERO == kTabcZero && TABC_BYTES == kTabcBytes, "image format");
+        static_assert(TABC_SMALL == kTabcSmall && TABC_SPLIT == kTabcSplit && TABC_BLOCKS == kTabcBlocks &&
+                      TABC_OFF_B == kTabcOffB && TABC_OFF_C == kTabcOffC && TABC_TABLE == kTabcTable &&
+                      TABC_BYTES == kTabcBytes && kTabcOffB >= (kTabcSmall + 1) * 4 &&
+                      kTabcOffC - kTabcOffB >= (kTabcSplit - kTabcSmall + 2) * 2 && kTabcBytes <= 160 * 1024,
+                      "image format");
         if ((rc = tab_c.ensure(kTabcBytes))) return rc;
         HIPCHK(hipMemcpy(tab_c.p, image.data(), kTabcBytes, hipMemcpyHostToDevice));
         if constexpr (ALG == ALG_TAB) {
-          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<8, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
-          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<16, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
-          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<32, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
-          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<0, TAB_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+          if (const char *e = getenv("LDPC_HIP_TAB_NT")) tab_nt = atoi(e) == 1024 ? 1024 : 512;
+          if (const char *e = getenv("LDPC_HIP_TAB_CH")) tab_rb = atoi(e);
+#define TAB_ATTR(RB, NT) HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<RB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes))
+#define TAB_ATTR3(RB) TAB_ATTR(RB, 512); TAB_ATTR(RB, 1024)
+          TAB_ATTR3(8); TAB_ATTR(16, 512);
+#undef TAB_ATTR3
+#undef TAB_ATTR
         }
         cn_variant = 6;
       }
@@ -370,17 +376,23 @@ struct BinaryEngine : Engine {
     if (cn_variant == 6) {
       // one workgroup per CU (its LDS holds the tables), TAB_NT / 64 waves each
       if constexpr (ALG == ALG_TAB) {
-        const int wpb = TAB_NT / 64;
+        // eight rows of a check in registers at a time, 8 waves per CU: measured best on every bench code
+        // (tools/probes/tab_sweep.sh: PEG-16000 6.48 Gbit/s; 16 rows 5.21, whole checks of 32 rows 5.30 -- the
+        // double-buffered chunks overlap the row loads with the lookups, a whole check in registers does not;
+        // 16 waves per CU spill: 5.30)
+        const int ch = tab_rb == 16 ? 16 : 8;
+        const int nt = (tab_nt == 1024 && ch == 8) ? 1024 : 512;
+        const int wpb = nt / 64;
         const int wps = balanced_wps(nslab, (long)num_cu * wpb * oversub);
         const long waves = (long)wps * nslab;
-        dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(TAB_NT);
-#define TAB_LAUNCH(RB)                                                                                     \
-  hipLaunchKernelGGL((cn_tab_lds_kernel<RB, TAB_NT>), grid, block, kTabcBytes, st, g, nslab, wps, msg.as<vec>(), \
+        dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(nt);
+#define TAB_LAUNCH(RB, NT)                                                                                 \
+  hipLaunchKernelGGL((cn_tab_lds_kernel<RB, NT>), grid, block, kTabcBytes, st, g, nslab, wps, msg.as<vec>(), \
                      hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab_c.as<uint32_t>())
-        if (rmax <= 8) TAB_LAUNCH(8);
-        else if (rmax <= 16) TAB_LAUNCH(16);
-        else if (rmax <= 32) TAB_LAUNCH(32);
-        else TAB_LAUNCH(0);
+#define TAB_LAUNCH3(RB) do { if (nt == 512) TAB_LAUNCH(RB, 512); else TAB_LAUNCH(RB, 1024); } while (0)
+        if (ch == 16) TAB_LAUNCH(16, 512);
+        else TAB_LAUNCH3(8);
+#undef TAB_LAUNCH3
 #undef TAB_LAUNCH
       }
       LAUNCHCHK("cn_tab_lds_kernel");

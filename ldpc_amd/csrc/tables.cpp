@@ -6,6 +6,7 @@
 // initlogexptab2() GFq_LDPC_NTT.c:196-219.
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "engine.h"
@@ -173,31 +174,35 @@ bool ldpc_build_spa_compact(const std::vector<int32_t> &flogtanh, const std::vec
   const int levels = 1 << (8 + kDeci);
   if ((int)flogtanh.size() != levels || (int)fgallag.size() != levels) return false;
   image.assign(kTabcBytes / 4, 0);
-  uint16_t *ab[2] = {reinterpret_cast<uint16_t *>(image.data()),
-                     reinterpret_cast<uint16_t *>(image.data()) + kTabcSplit};
-  uint32_t *cb[2] = {image.data() + kTabcSplit, image.data() + kTabcSplit + kTabcBlocks};
   for (int t = 0; t < 2; t++) {
     const std::vector<int32_t> &src = t ? fgallag : flogtanh;
     auto mag = [&](int i) { return t ? src[(size_t)i] : -src[(size_t)i]; };
-    if (mag(0) != kTabcZero) return false;
-    for (int i = 1; i < kTabcSplit; i++) {
-      int e = 0;
-      while ((i >> (e + 1)) != 0) e++;
-      const int r = mag(i) - (kTabcC0 - kTabcM * e);
-      if (r < 0 || r > 65535) return false;
-      ab[t][i] = (uint16_t)r;
+    unsigned char *base = reinterpret_cast<unsigned char *>(image.data()) + (size_t)t * kTabcTable;
+    uint32_t *a32 = reinterpret_cast<uint32_t *>(base);
+    uint16_t *b16 = reinterpret_cast<uint16_t *>(base + kTabcOffB);
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(base + kTabcOffC);
+    for (int i = 0; i < kTabcSmall; i++) {
+      if (mag(i) < 0) return false;
+      a32[i] = (uint32_t)mag(i);
     }
+    a32[kTabcSmall] = 0;
+    b16[0] = 0;                                             // (entry 2047)
+    for (int i = kTabcSmall; i < kTabcSplit; i++) {
+      if (mag(i) < 0 || mag(i) > 65535) return false;
+      b16[i - (kTabcSmall - 1)] = (uint16_t)mag(i);
+    }
+    b16[kTabcSplit - (kTabcSmall - 1)] = 0;
     for (int b = 0; b < kTabcBlocks; b++) {
       const int i0 = kTabcSplit + 16 * b;
-      const int base = mag(i0 - 1);
-      if (base < 0 || base > 65535) return false;
-      uint32_t w = (uint32_t)base << 16;
+      const int start = mag(i0 - 1);
+      if (start < 0 || start > 65535) return false;
+      uint32_t w = (uint32_t)start << 16;
       for (int k = 0; k < 16; k++) {
         const int step = mag(i0 + k - 1) - mag(i0 + k);
         if (step != 0 && step != 1) return false;
         w |= (uint32_t)step << k;
       }
-      cb[t][b] = w;
+      c32[b] = w;
     }
     for (int i = kTabcEnd - 1; i < levels; i++)
       if (src[(size_t)i] != 0) return false;
@@ -206,20 +211,17 @@ bool ldpc_build_spa_compact(const std::vector<int32_t> &flogtanh, const std::vec
 }
 
 int ldpc_spa_compact_mag(const uint32_t *image, int table, unsigned i) {
-  const uint16_t *ab = reinterpret_cast<const uint16_t *>(image) + (table ? kTabcSplit : 0);
-  const uint32_t *cb = image + kTabcSplit + (table ? kTabcBlocks : 0);
-  const unsigned ia = i < (unsigned)kTabcSplit ? i : (unsigned)kTabcSplit - 1;
-  int e = 0;
-  while (((ia | 1u) >> (e + 1)) != 0) e++;
-  int va = (int)ab[ia] + (kTabcC0 - kTabcM * e);
-  if (i == 0) va = kTabcZero;
-  unsigned j = i < (unsigned)kTabcSplit ? 0u : i - (unsigned)kTabcSplit;
-  if (j > 16u * kTabcBlocks - 1) j = 16u * kTabcBlocks - 1;
-  const uint32_t w = cb[j >> 4];
-  const int vc = (int)(w >> 16) - __builtin_popcount(w & ((2u << (j & 15u)) - 1u));
-  int r = i < (unsigned)kTabcSplit ? va : vc;
-  if (i >= (unsigned)kTabcEnd) r = 0;
-  return r;
+  const unsigned char *t = reinterpret_cast<const unsigned char *>(image) + (size_t)table * kTabcTable;
+  auto umin = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  uint32_t a, w;
+  uint16_t bq;
+  const unsigned ia = umin(i, kTabcSmall);
+  const unsigned ib = i < (unsigned)kTabcSmall - 1 ? (unsigned)kTabcSmall - 1 : umin(i, kTabcSplit);
+  const unsigned j = umin(i - (unsigned)kTabcSplit, 16u * kTabcBlocks - 1u);
+  std::memcpy(&a, t + 4 * ia, 4);
+  std::memcpy(&bq, t + (kTabcOffB - 2 * (kTabcSmall - 1)) + 2 * ib, 2);
+  std::memcpy(&w, t + kTabcOffC + ((j >> 2) & ~3u), 4);
+  return (int)(a + bq + (w >> 16)) - __builtin_popcount(w & ((2u << (j & 15u)) - 1u));
 }
 
 long ldpc_spa_compact_selfcheck(long stats[4]) {
