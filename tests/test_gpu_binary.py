@@ -162,6 +162,40 @@ def test_spa_table(hip, oracle, name, F, p, sigma, it):
     check_exact(dec.decode(llr, s.astype(np.uint8), it), ref, f"tab {name} f64")
 
 
+def test_spa_table_on_ragged_rows(hip, oracle, tmp_path):
+    """The table sum-product's LDS-table kernel takes a check's rows in chunks of eight (one chunk for
+    row weights <= 8, else two sweeps of double-buffered chunks whose last one is filled up with copies
+    of the last row): one code with every row weight from 1 to 45 walks through every remainder, for
+    both chunk sizes the kernel is built with."""
+    import os
+    rng = np.random.default_rng(4242)
+    n = 360
+    rows = [rng.choice(n, 1 + (j % 45), replace=False) for j in range(90)]
+    rows += [np.arange(8 * j, 8 * j + 8) for j in range(n // 8)]          # every variable is in some check
+    H = np.zeros((len(rows), n), np.uint8)
+    for j, r in enumerate(rows):
+        H[j, r] = 1
+    path = str(tmp_path / "ragged.alist")
+    hip.alist.matrix_to_alist(H, path)
+    oc = oracle.load(path)
+    code = hip.Code.from_alist(path)
+    x, s, llr = make_frames(oracle, oc, 300, 0.03, 9, "bsc")
+    q14 = oracle.float2fix14(llr)
+    ref = run_oracle(oracle.dec_spa_table, oc, q14, s, 12)
+    ok = ref[3] >= 0                  # (rc -2: the reference itself indexed outside its table)
+    assert ok.sum() >= 250
+    ref = tuple(r[ok] for r in ref)
+    for ch in ("8", "16"):
+        os.environ["LDPC_HIP_TAB_CH"] = ch
+        try:
+            dec = hip.Decoder(code, hip.ALG.SPA_TABLE_Q14, max_frames=512, early_exit=True)
+        finally:
+            del os.environ["LDPC_HIP_TAB_CH"]
+        out = dec.decode(q14, s.astype(np.uint8), 12)
+        check_exact({k: v[ok] for k, v in out.items()}, ref, f"table ragged rows, chunks of {ch}")
+    assert len(set(ref[1].tolist())) > 2, "frames should stop at different iterations"
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("name,F,p,it", [("204.33.484.txt", 200, 0.05, 15), ("peg_16000_3_0.9.txt", 9, 0.0015, 8),
                                          ("Frolov_1024_0.5.txt", 40, 0.045, 20)])
