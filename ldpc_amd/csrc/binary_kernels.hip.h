@@ -255,14 +255,84 @@ __device__ __forceinline__ float spa_logtanh2(float a) {
     num = a * (1.0f - a * (0.5f - a * (1.0f / 6.0f - a * (1.0f / 24.0f - a * (1.0f / 120.0f - a * (1.0f / 720.0f))))));
   return spa_flog(num * __builtin_amdgcn_rcpf(1.0f + t));
 }
-__device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
 __device__ __forceinline__ float spa_atanh2exp(float x) {
   const float e = spa_fexp(x);
   if (x < -3.0f) { const float e2 = e * e; return 2.0f * e * (1.0f + e2 * (1.0f / 3.0f + e2 * 0.2f)); }
   if (x > -0.1f) return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
   return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(1.0f - e));
 }
+// binary64: both functions are +-G(x) = log((1 + e^x) / (1 - e^x)), x <= 0 (log tanh(a/2) = -G(-a)).  The
+// device library's tanh / exp / log and the IEEE division sequence made the literal formulas ~165 binary64
+// instructions per value; G is evaluated here in ~70 with the SAME structure as the reference's arithmetic
+// (test_code_B_float.c:20-27): e = exp(x) rounded to binary64 (k ln 2 split in two, a degree-13 expm1
+// polynomial, v_ldexp), then 1 + e and 1 - e rounded, so the quantisation of 1 - e near x = 0, the
+// saturation to 0 once e < 2^-53 (|x| > 37) and G(0) = +inf are the reference's; the logarithm of the quotient
+// is taken without forming the quotient: both mantissas are brought within sqrt 2 of each other,
+// s = (mn - md) / (mn + md) by one reciprocal + Newton steps, log = k ln 2 + 2 atanh(s) by its series to
+// s^21.  Worst relative error against exact arithmetic 4.4e-13 on [-9, -5e-13] (the literal glibc forms:
+// 2.2e-13 / 8.3e-13; both are the rounding of 1 -+ e), NaN in -> NaN out, -inf -> 0.
+// ACC: 1 - e taken from the polynomial where k = 0 (log tanh of a tiny argument stays exact, as glibc's tanh is).
+#ifndef LDPC_SPA_F64_LIBM
+template <bool ACC>
+__device__ __forceinline__ double spa_G64(double xin) {
+  const double x = xin < -750.0 ? -750.0 : xin;
+  const double kf = __builtin_rint(x * 1.4426950408889634);
+  const int k = (int)kf;
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  double q = 1.0 / 6227020800.0;
+  q = __builtin_fma(q, r, 1.0 / 479001600.0);
+  q = __builtin_fma(q, r, 1.0 / 39916800.0);
+  q = __builtin_fma(q, r, 1.0 / 3628800.0);
+  q = __builtin_fma(q, r, 1.0 / 362880.0);
+  q = __builtin_fma(q, r, 1.0 / 40320.0);
+  q = __builtin_fma(q, r, 1.0 / 5040.0);
+  q = __builtin_fma(q, r, 1.0 / 720.0);
+  q = __builtin_fma(q, r, 1.0 / 120.0);
+  q = __builtin_fma(q, r, 1.0 / 24.0);
+  q = __builtin_fma(q, r, 1.0 / 6.0);
+  q = __builtin_fma(q, r, 0.5);
+  const double p = __builtin_fma(q * r, r, r);              // expm1(r)
+  const double e = __builtin_ldexp(1.0 + p, k);
+  const double num = 1.0 + e;
+  const double den = (ACC && k == 0) ? -p : 1.0 - e;
+  double mn = __builtin_amdgcn_frexp_mant(num), md = __builtin_amdgcn_frexp_mant(den);
+  int k2 = __builtin_amdgcn_frexp_exp(num) - __builtin_amdgcn_frexp_exp(den);
+  const int an = mn < md * 0.70710678118654752440 ? 1 : 0;
+  const int ad = mn > md * 1.41421356237309504880 ? 1 : 0;
+  mn = __builtin_ldexp(mn, an);
+  md = __builtin_ldexp(md, ad);
+  k2 += ad - an;
+  const double a = mn - md, b = mn + md;                    // b in (0.7, 3)
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  double s = a * y;
+  s = __builtin_fma(__builtin_fma(-s, b, a), y, s);
+  const double z = s * s;
+  double t = 1.0 / 21.0;
+  t = __builtin_fma(t, z, 1.0 / 19.0);
+  t = __builtin_fma(t, z, 1.0 / 17.0);
+  t = __builtin_fma(t, z, 1.0 / 15.0);
+  t = __builtin_fma(t, z, 1.0 / 13.0);
+  t = __builtin_fma(t, z, 1.0 / 11.0);
+  t = __builtin_fma(t, z, 1.0 / 9.0);
+  t = __builtin_fma(t, z, 1.0 / 7.0);
+  t = __builtin_fma(t, z, 1.0 / 5.0);
+  t = __builtin_fma(t, z, 1.0 / 3.0);
+  const double s2 = s + s, k2f = (double)k2;
+  double res = __builtin_fma(s2 * z, t, __builtin_fma(k2f, 1.90821492927058770002e-10, s2));
+  res = __builtin_fma(k2f, 6.93147180369123816490e-01, res);
+  res = den == 0.0 ? __builtin_huge_val() : res;
+  res = xin != xin ? xin : res;
+  return res;
+}
+__device__ __forceinline__ double spa_logtanh2(double a) { return -spa_G64<true>(-a); }
+__device__ __forceinline__ double spa_atanh2exp(double x) { return spa_G64<false>(x); }
+#else   // the literal formulas on the device library (A/B builds)
+__device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
 __device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
+#endif
 
 // Flogtanh / Fgallag (test_code_B.c:76-90)
 __device__ __forceinline__ int tab_logtanh(const Tables &t, int a) {

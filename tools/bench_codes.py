@@ -28,7 +28,7 @@ def main():
     rows = [("peg_16000_3_0.9.txt", 0.02), ("32000.2240.3.105.txt", 0.02), ("4095.737.3.txt", 0.03),
             ("1057.244.3.txt", 0.04), ("Frolov_1024_0.5.txt", 0.12), ("204.33.484.txt", 0.12), ("dvb_H_0.5.txt", 0.12)]
     algs = [("MINSUM_Q88", DT.I16, torch.int16), ("MINSUM_F32", DT.F32, torch.float32),
-            ("MINSUM_F64", DT.F64, torch.float64), ("SPA_F32", DT.F32, torch.float32),
+            ("MINSUM_F64", DT.F64, torch.float64), ("SPA_F32", DT.F32, torch.float32), ("SPA_F64", DT.F64, torch.float64),
             ("SPA_TABLE_Q14", DT.I32, torch.int32)]
     want_code = sys.argv[1] if len(sys.argv) > 1 else ""
     want_alg = sys.argv[2] if len(sys.argv) > 2 else ""
