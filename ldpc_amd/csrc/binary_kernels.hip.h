@@ -261,23 +261,27 @@ __device__ __forceinline__ float spa_atanh2exp(float x) {
   if (x > -0.1f) return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(fabsf(x) * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f + x * (1.0f / 120.0f)))))));   /* x = 0: log(2 / +0) = +inf like the reference */
   return spa_flog((1.0f + e) * __builtin_amdgcn_rcpf(1.0f - e));
 }
-// binary64: both functions are +-G(x) = log((1 + e^x) / (1 - e^x)), x <= 0 (log tanh(a/2) = -G(-a)).  The
-// device library's tanh / exp / log and the IEEE division sequence made the literal formulas ~165 binary64
-// instructions per value; G is evaluated here in ~70 with the SAME structure as the reference's arithmetic
-// (test_code_B_float.c:20-27): e = exp(x) rounded to binary64 (k ln 2 split in two, a degree-13 expm1
-// polynomial, v_ldexp), then 1 + e and 1 - e rounded, so the quantisation of 1 - e near x = 0, the
-// saturation to 0 once e < 2^-53 (|x| > 37) and G(0) = +inf are the reference's; the logarithm of the quotient
-// is taken without forming the quotient: both mantissas are brought within sqrt 2 of each other,
-// s = (mn - md) / (mn + md) by one reciprocal + Newton steps, log = k ln 2 + 2 atanh(s) by its series to
-// s^21.  Worst relative error against exact arithmetic 4.4e-13 on [-9, -5e-13] (the literal glibc forms:
-// 2.2e-13 / 8.3e-13; both are the rounding of 1 -+ e), NaN in -> NaN out, -inf -> 0.
-// ACC: 1 - e taken from the polynomial where k = 0 (log tanh of a tiny argument stays exact, as glibc's tanh is).
+// binary64.  The device library's tanh / exp / log and the IEEE division sequence made the literal formulas
+// ~165 binary64 instructions per value; they are evaluated here in ~70 with the SAME rounding structure as the
+// reference's arithmetic (test_code_B_float.c:20-27), because that structure is behaviour: the quantisation of
+// tanh near 1 and of 1 - e^x near x = 0 decide where a message saturates to 0 / +inf and the inf - inf = NaN
+// hazard fires (the error floor of the DVB-S2 sweeps).
+//   spa_exp64:  e^x for x <= 0 as (1 + p) 2^k: k ln 2 split in two, degree-13 polynomial p = expm1(r), v_ldexp
+//   spa_div64:  one v_rcp_f64, two Newton steps, one residual correction
+//   spa_logq64: log(num / den) without forming the quotient: both mantissas brought within sqrt 2 of each other,
+//               s = (mn - md) / (mn + md), log = k ln 2 + 2 atanh(s) by its series to s^21
+//   log tanh(a/2): t = tanh(a/2) ROUNDED to binary64 first, as glibc's is: 1 - 2u / (1 + u) with u = e^-a (so t = 1,
+//               the message's weight 0, exactly when u < 2^-55, a > 38.1), -p / (2 + p) where k = 0 (exact for tiny a);
+//               then log t
+//   atanh2(e^x): e = e^x rounded, then 1 + e and 1 - e rounded (x -> 0: the reference's cancellation, +inf at 0), then
+//               the log of their quotient
+// Worst relative error against exact arithmetic 4.4e-13 on [-9, -5e-13] (the literal glibc forms: 2.2e-13 / 8.3e-13:
+// all of it the rounding of 1 -+ e); NaN in -> NaN out, -inf -> 0.
 #ifndef LDPC_SPA_F64_LIBM
-template <bool ACC>
-__device__ __forceinline__ double spa_G64(double xin) {
-  const double x = xin < -750.0 ? -750.0 : xin;
+__device__ __forceinline__ double spa_exp64(double x, double &p, int &k) {
+  x = x < -750.0 ? -750.0 : x;
   const double kf = __builtin_rint(x * 1.4426950408889634);
-  const int k = (int)kf;
+  k = (int)kf;
   double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
   r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
   double q = 1.0 / 6227020800.0;
@@ -292,10 +296,17 @@ __device__ __forceinline__ double spa_G64(double xin) {
   q = __builtin_fma(q, r, 1.0 / 24.0);
   q = __builtin_fma(q, r, 1.0 / 6.0);
   q = __builtin_fma(q, r, 0.5);
-  const double p = __builtin_fma(q * r, r, r);              // expm1(r)
-  const double e = __builtin_ldexp(1.0 + p, k);
-  const double num = 1.0 + e;
-  const double den = (ACC && k == 0) ? -p : 1.0 - e;
+  p = __builtin_fma(q * r, r, r);
+  return __builtin_ldexp(1.0 + p, k);
+}
+__device__ __forceinline__ double spa_div64(double a, double b) {   // b finite, normal, non-zero
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  const double s = a * y;
+  return __builtin_fma(__builtin_fma(-s, b, a), y, s);
+}
+__device__ __forceinline__ double spa_logq64(double num, double den) {   // num, den > 0
   double mn = __builtin_amdgcn_frexp_mant(num), md = __builtin_amdgcn_frexp_mant(den);
   int k2 = __builtin_amdgcn_frexp_exp(num) - __builtin_amdgcn_frexp_exp(den);
   const int an = mn < md * 0.70710678118654752440 ? 1 : 0;
@@ -303,12 +314,7 @@ __device__ __forceinline__ double spa_G64(double xin) {
   mn = __builtin_ldexp(mn, an);
   md = __builtin_ldexp(md, ad);
   k2 += ad - an;
-  const double a = mn - md, b = mn + md;                    // b in (0.7, 3)
-  double y = __builtin_amdgcn_rcp(b);
-  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
-  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
-  double s = a * y;
-  s = __builtin_fma(__builtin_fma(-s, b, a), y, s);
+  const double s = spa_div64(mn - md, mn + md);               // (mn + md in (0.7, 3))
   const double z = s * s;
   double t = 1.0 / 21.0;
   t = __builtin_fma(t, z, 1.0 / 19.0);
@@ -321,14 +327,26 @@ __device__ __forceinline__ double spa_G64(double xin) {
   t = __builtin_fma(t, z, 1.0 / 5.0);
   t = __builtin_fma(t, z, 1.0 / 3.0);
   const double s2 = s + s, k2f = (double)k2;
-  double res = __builtin_fma(s2 * z, t, __builtin_fma(k2f, 1.90821492927058770002e-10, s2));
-  res = __builtin_fma(k2f, 6.93147180369123816490e-01, res);
-  res = den == 0.0 ? __builtin_huge_val() : res;
-  res = xin != xin ? xin : res;
-  return res;
+  const double res = __builtin_fma(s2 * z, t, __builtin_fma(k2f, 1.90821492927058770002e-10, s2));
+  return __builtin_fma(k2f, 6.93147180369123816490e-01, res);
 }
-__device__ __forceinline__ double spa_logtanh2(double a) { return -spa_G64<true>(-a); }
-__device__ __forceinline__ double spa_atanh2exp(double x) { return spa_G64<false>(x); }
+__device__ __forceinline__ double spa_logtanh2(double a) {            // a >= 0 (or NaN)
+  double p; int k;
+  const double u = spa_exp64(-a, p, k);
+  const double qd = spa_div64(k == 0 ? -p : u + u, k == 0 ? 2.0 + p : 1.0 + u);
+  const double t = k == 0 ? qd : 1.0 - qd;                             // tanh(a/2), rounded
+  double res = spa_logq64(t, 1.0);
+  res = t == 0.0 ? -__builtin_huge_val() : res;
+  return a != a ? a : res;
+}
+__device__ __forceinline__ double spa_atanh2exp(double x) {           // x <= 0 (or NaN)
+  double p; int k;
+  const double e = spa_exp64(x, p, k);
+  const double den = 1.0 - e;
+  double res = spa_logq64(1.0 + e, den);
+  res = den == 0.0 ? __builtin_huge_val() : res;
+  return x != x ? x : res;
+}
 #else   // the literal formulas on the device library (A/B builds)
 __device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
 __device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
