@@ -837,6 +837,7 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
       vec xa[CH], xb[CH];
       unsigned ha[CH], hbb[CH];
       load(0, xa, ha, true);
+      int ka = 0;                      // the chunk xa holds when the sweep ends (xb: the one after it, if any)
       for (int k0 = 0; k0 < dc; k0 += 2 * CH) {
         const bool second = k0 + CH < dc;
         if (second) load(k0 + CH, xb, hbb, true);
@@ -845,6 +846,7 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
           if (k0 + 2 * CH < dc) load(k0 + 2 * CH, xa, ha, true);
           sweep1(k0 + CH, xb, hbb, std::false_type());
         }
+        ka = k0;
       }
       failacc |= par;
       auto sweep2 = [&](int k0, vec (&x)[CH]) {
@@ -863,15 +865,17 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
           store(k0, c, o);
         }
       };
-      load(0, xa, ha, false);
-      for (int k0 = 0; k0 < dc; k0 += 2 * CH) {
-        const bool second = k0 + CH < dc;
-        if (second) load(k0 + CH, xb, hbb, false);
+      // second sweep: the last one or two chunks are still in registers (no second read for them:
+      // all of it for row weights <= 16); the chunks before them are read again, double-buffered
+      const bool tail_b = ka + CH < dc;
+      sweep2(ka, xa);
+      if (ka > 0) load(0, xa, ha, false);
+      if (tail_b) sweep2(ka + CH, xb);
+      for (int k0 = 0; k0 < ka; k0 += 2 * CH) {        // (ka is a multiple of 2 CH)
+        load(k0 + CH, xb, hbb, false);
         sweep2(k0, xa);
-        if (second) {
-          if (k0 + 2 * CH < dc) load(k0 + 2 * CH, xa, ha, false);
-          sweep2(k0 + CH, xb);
-        }
+        if (k0 + 2 * CH < ka) load(k0 + 2 * CH, xa, ha, false);
+        sweep2(k0 + CH, xb);
       }
     }
   }

@@ -312,7 +312,7 @@ struct BinaryEngine : Engine {
           if (const char *e = getenv("LDPC_HIP_TAB_CH")) tab_rb = atoi(e);
 #define TAB_ATTR(RB, NT) HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<RB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes))
 #define TAB_ATTR3(RB) TAB_ATTR(RB, 512); TAB_ATTR(RB, 1024)
-          TAB_ATTR3(8); TAB_ATTR(16, 512);
+          TAB_ATTR3(8); TAB_ATTR(16, 512); TAB_ATTR3(4);
 #undef TAB_ATTR3
 #undef TAB_ATTR
         }
@@ -376,12 +376,14 @@ struct BinaryEngine : Engine {
     if (cn_variant == 6) {
       // one workgroup per CU (its LDS holds the tables), TAB_NT / 64 waves each
       if constexpr (ALG == ALG_TAB) {
-        // eight rows of a check in registers at a time, 8 waves per CU: measured best on every bench code
-        // (tools/probes/tab_sweep.sh: PEG-16000 6.48 Gbit/s; 16 rows 5.21, whole checks of 32 rows 5.30 -- the
-        // double-buffered chunks overlap the row loads with the lookups, a whole check in registers does not;
-        // 16 waves per CU spill: 5.30)
-        const int ch = tab_rb == 16 ? 16 : 8;
-        const int nt = (tab_nt == 1024 && ch == 8) ? 1024 : 512;
+        // rows of a check in registers at a time / waves per CU (tools/probes/tab_sweep.sh, PEG-16000 Gbit/s):
+        // 4 / 16: 6.88, 8 / 8: 6.50, 4 / 8: 6.52, 16 / 8: 5.21, whole checks of 32 rows / 8: 5.30, 8 / 16 (spills): 5.30
+        // -- the double-buffered chunks overlap the row loads with the lookups, a whole check in registers does
+        // not.  Row weights <= 8 (DVB-S2): one chunk of eight holds the check and keeps its log tanh values.
+        int ch = rmax <= 8 ? 8 : 4;
+        if (tab_rb == 4 || tab_rb == 8 || tab_rb == 16) ch = tab_rb;
+        int nt = ch == 4 ? 1024 : 512;
+        if (tab_nt > 0 && ch <= 8) nt = tab_nt;
         const int wpb = nt / 64;
         const int wps = balanced_wps(nslab, (long)num_cu * wpb * oversub);
         const long waves = (long)wps * nslab;
@@ -391,6 +393,7 @@ struct BinaryEngine : Engine {
                      hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab_c.as<uint32_t>())
 #define TAB_LAUNCH3(RB) do { if (nt == 512) TAB_LAUNCH(RB, 512); else TAB_LAUNCH(RB, 1024); } while (0)
         if (ch == 16) TAB_LAUNCH(16, 512);
+        else if (ch == 4) TAB_LAUNCH3(4);
         else TAB_LAUNCH3(8);
 #undef TAB_LAUNCH3
 #undef TAB_LAUNCH

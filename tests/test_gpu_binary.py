@@ -163,10 +163,10 @@ def test_spa_table(hip, oracle, name, F, p, sigma, it):
 
 
 def test_spa_table_on_ragged_rows(hip, oracle, tmp_path):
-    """The table sum-product's LDS-table kernel takes a check's rows in chunks of eight (one chunk for
-    row weights <= 8, else two sweeps of double-buffered chunks whose last one is filled up with copies
-    of the last row): one code with every row weight from 1 to 45 walks through every remainder, for
-    both chunk sizes the kernel is built with."""
+    """The table sum-product's LDS-table kernel takes a check's rows in chunks (one chunk when it holds the
+    whole check, else two sweeps of double-buffered chunks whose last one is filled up with copies of the
+    last row and whose last two are not read again): one code with every row weight from 1 to 45 walks
+    through every remainder, for the three chunk sizes the kernel is built with."""
     import os
     rng = np.random.default_rng(4242)
     n = 360
@@ -185,7 +185,7 @@ def test_spa_table_on_ragged_rows(hip, oracle, tmp_path):
     ok = ref[3] >= 0                  # (rc -2: the reference itself indexed outside its table)
     assert ok.sum() >= 250
     ref = tuple(r[ok] for r in ref)
-    for ch in ("8", "16"):
+    for ch in ("4", "8", "16"):
         os.environ["LDPC_HIP_TAB_CH"] = ch
         try:
             dec = hip.Decoder(code, hip.ALG.SPA_TABLE_Q14, max_frames=512, early_exit=True)

@@ -1,6 +1,6 @@
-# cn_tab_lds_kernel: threads per workgroup (and rows per chunk) on the bench codes
+# cn_tab_lds_kernel: threads per workgroup and rows per chunk on the bench codes
 set -e
-for cfg in "512 -1" "1024 -1" "512 8" "512 16"; do
+for cfg in "512 8" "512 4" "1024 4"; do
   set -- $cfg
   echo "NT=$1 CH=$2"
   for code in peg_16000 32000 dvb 1057 Frolov; do
