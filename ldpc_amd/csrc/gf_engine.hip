@@ -776,27 +776,40 @@ __global__ __launch_bounds__(256) void gfq_vn_kernel(GGraph g, int nfg, const do
 // enc() (GFq_LDPC.c:299-310) of the current estimate and the distance to the
 // target syndrome: bit count for GF(2^p) (HamDist, GFq_LDPC_NTT.c:253-262),
 // symbol count otherwise.  One thread per (check, frame); frames across lanes.
-// a thread: one frame, `per` consecutive checks (up to 32, fewer when the launch would otherwise be
-// small) -- one atomic on the frame's distance per thread (one per unsatisfied check and frame
-// queued thousands deep on a frame's word when nothing converges)
-__global__ __launch_bounds__(256) void gf_synd_kernel(GGraph g, const uint8_t *__restrict__ xhat,
+// A workgroup: 64 frames (one per lane) x `per` consecutive checks, dealt round-robin to its 8 wavefronts;
+// the wavefronts' partial distances meet in LDS and make ONE atomic per frame and workgroup (one per
+// unsatisfied check and frame queued thousands deep on a frame's word when nothing converges).  Round 2's
+// first version gave a thread 32 checks in a row: ~190 dependent loads one after the other, 139 us per
+// launch on the GF(4) bench where the bytes would take 15 (profiles/r02_gf4_wht_counters.txt).
+#define GF_SYND_WAVES 8
+__global__ __launch_bounds__(64 * GF_SYND_WAVES) void gf_synd_kernel(GGraph g, const uint8_t *__restrict__ xhat,
                                                       const uint8_t *__restrict__ synd,
                                                       uint8_t *__restrict__ zhat, int *__restrict__ dist,
                                                       const uint8_t *__restrict__ frozen, int per) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= g.Fpad || frozen[f]) return;
+  __shared__ int part[GF_SYND_WAVES][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  const bool live = f < g.Fpad && !frozen[f];
   const int j0 = blockIdx.y * per, j1 = min(j0 + per, g.m);
   int dsum = 0;
-  for (int j = j0; j < j1; j++) {
-    const size_t idx = (size_t)j * g.Fpad + f;
-    int sum = 0;
-    for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++)
-      sum = gf_add(g, sum, g.mul[xhat[(size_t)g.col_idx[e] * g.Fpad + f] * g.Q + g.hval[e]]);
-    zhat[idx] = (uint8_t)sum;
-    const int z = synd ? synd[idx] : 0;
-    dsum += g.pow2 ? __popc((unsigned)(z ^ sum)) : (z != sum);
+  if (live)
+    for (int j = j0 + grp; j < j1; j += GF_SYND_WAVES) {
+      const size_t idx = (size_t)j * g.Fpad + f;
+      int sum = 0;
+      for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++)
+        sum = gf_add(g, sum, g.mul[xhat[(size_t)g.col_idx[e] * g.Fpad + f] * g.Q + g.hval[e]]);
+      zhat[idx] = (uint8_t)sum;
+      const int z = synd ? synd[idx] : 0;
+      dsum += g.pow2 ? __popc((unsigned)(z ^ sum)) : (z != sum);
+    }
+  part[grp][lane] = dsum;
+  __syncthreads();
+  if (grp == 0 && live) {
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < GF_SYND_WAVES; k++) tot += part[k][lane];
+    if (tot) atomicAdd(&dist[f], tot);
   }
-  if (dsum) atomicAdd(&dist[f], dsum);
 }
 
 struct FrameState {
@@ -1168,8 +1181,8 @@ struct GfEngine : Engine {
                            ra.as<double>(), qa.as<double>(), xhat.as<uint8_t>(), fs.frozen);
       LAUNCHCHK("gf vn kernel");
       prof_end(st);
-      const int synd_per = (int)std::max<size_t>(1, std::min<size_t>(32, (size_t)m * Fpad / (256 * 2048)));
-      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)((Fpad + 255) / 256), (unsigned)((m + synd_per - 1) / synd_per)), dim3(256), 0, st, gg,
+      const int synd_per = (int)std::max<size_t>(GF_SYND_WAVES, std::min<size_t>(64, (size_t)m * Fpad / (64 * 1024)));
+      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)((Fpad + 63) / 64), (unsigned)((m + synd_per - 1) / synd_per)), dim3(64 * GF_SYND_WAVES), 0, st, gg,
                          xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen, synd_per);
       LAUNCHCHK("gf_synd_kernel");
       hipLaunchKernelGGL(gf_state_kernel, dim3((Fpad + 255) / 256), dim3(256), 0, st, fs, Fpad, t, WHT ? 1 : 0,
