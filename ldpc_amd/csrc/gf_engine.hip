@@ -191,6 +191,20 @@ __global__ void gf_init_kernel(GGraph g, const T *__restrict__ fna, T *__restric
   }
 }
 
+// The same, one workgroup per edge: the edge and its variable are wave-uniform (no 64-bit division, no
+// gather of col_idx per element) and a variable's row goes out in 16-byte pieces.  For rows whose size is
+// a multiple of 16 bytes.  528 -> see profiles/r02_gf4_wht_counters.txt
+template <typename T>
+__global__ __launch_bounds__(256) void gf_init_rows_kernel(GGraph g, const T *__restrict__ fna, T *__restrict__ qa) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const size_t per16 = (size_t)g.Fpad * g.Q * sizeof(T) / 16;
+  for (int e = blockIdx.x; e < g.E; e += gridDim.x) {
+    const u4 *src = reinterpret_cast<const u4 *>(fna) + (size_t)g.col_idx[e] * per16;
+    u4 *dst = reinterpret_cast<u4 *>(qa) + (size_t)e * per16;
+    for (size_t t = threadIdx.x; t < per16; t += 256) dst[t] = src[t];
+  }
+}
+
 // ---------------------------------------------------- GF(2^p) WHT check node
 //
 // One wave per (check j, group of G frames).  GFq_LDPC_NTT.c:449-484.
@@ -812,6 +826,60 @@ __global__ __launch_bounds__(64 * GF_SYND_WAVES) void gf_synd_kernel(GGraph g, c
   }
 }
 
+// The same with FOUR frames per lane (one 32-bit access per row instead of four byte accesses, which the
+// texture-address unit takes at a quarter of the dword rate) and the multiplication table in LDS (the global
+// gather per edge and frame depended on the byte just loaded): fields up to GF(16), frame count a multiple of 4.
+__global__ __launch_bounds__(64 * GF_SYND_WAVES) void gf_synd4_kernel(GGraph g, const uint8_t *__restrict__ xhat,
+                                                       const uint8_t *__restrict__ synd,
+                                                       uint8_t *__restrict__ zhat, int *__restrict__ dist,
+                                                       const uint8_t *__restrict__ frozen, int per) {
+  __shared__ int part[GF_SYND_WAVES][4][64];
+  __shared__ uint8_t mulL[256];
+  if ((int)threadIdx.x < g.Q * g.Q) mulL[threadIdx.x] = g.mul[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int f0 = (blockIdx.x * 64 + lane) * 4;
+  unsigned livem = 0;                       // bit k: frame f0 + k is still being decoded
+  if (f0 < g.Fpad) {
+    const unsigned fr = *reinterpret_cast<const uint32_t *>(frozen + f0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) livem |= (((fr >> (8 * k)) & 0xffu) ? 0u : 1u) << k;
+  }
+  const int j0 = blockIdx.y * per, j1 = min(j0 + per, g.m);
+  int ds[4] = {0, 0, 0, 0};
+  if (livem)
+    for (int j = j0 + grp; j < j1; j += GF_SYND_WAVES) {
+      const size_t idx = (size_t)j * g.Fpad + f0;
+      int sum[4] = {0, 0, 0, 0};
+      for (int e = g.row_ptr[j]; e < g.row_ptr[j + 1]; e++) {
+        const unsigned x = *reinterpret_cast<const uint32_t *>(xhat + (size_t)g.col_idx[e] * g.Fpad + f0);
+        const int h = g.hval[e];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sum[k] = gf_add(g, sum[k], mulL[((x >> (8 * k)) & 0xffu) * g.Q + h]);
+      }
+      const unsigned z = synd ? *reinterpret_cast<const uint32_t *>(synd + idx) : 0u;
+      unsigned out = livem == 15u ? 0u : *reinterpret_cast<const uint32_t *>(zhat + idx);   // frozen frames keep theirs
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if ((livem >> k) & 1u) {
+          const int zk = (int)((z >> (8 * k)) & 0xffu);
+          out = (out & ~(0xffu << (8 * k))) | ((unsigned)sum[k] << (8 * k));
+          ds[k] += g.pow2 ? __popc((unsigned)(zk ^ sum[k])) : (zk != sum[k]);
+        }
+      }
+      *reinterpret_cast<uint32_t *>(zhat + idx) = out;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; k++) part[grp][k][lane] = ds[k];
+  __syncthreads();
+  if (grp < 4 && ((livem >> grp) & 1u)) {   // wavefront k sums frame f0 + k of every lane
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < GF_SYND_WAVES; w++) tot += part[w][grp][lane];
+    if (tot) atomicAdd(&dist[f0 + grp], tot);
+  }
+}
+
 struct FrameState {
   int32_t *dist, *iters, *status, *iir, *prev, *nodecr;
   uint8_t *frozen;
@@ -1114,7 +1182,11 @@ struct GfEngine : Engine {
       LAUNCHCHK("gf_sym_in_kernel");
       sy = synd.as<uint8_t>();
     }
-    hipLaunchKernelGGL((gf_init_kernel<T>), dim3(blocks_for((size_t)E * Fpad * Q, 256)), dim3(256), 0, st, gg,
+    if (((size_t)Fpad * Q * sizeof(T)) % 16 == 0)
+      hipLaunchKernelGGL((gf_init_rows_kernel<T>), dim3((unsigned)std::min<size_t>((size_t)E, (size_t)num_cu * 64)), dim3(256), 0, st, gg,
+                       fna.as<T>(), qa.as<T>());
+    else
+      hipLaunchKernelGGL((gf_init_kernel<T>), dim3(blocks_for((size_t)E * Fpad * Q, 256)), dim3(256), 0, st, gg,
                        fna.as<T>(), qa.as<T>());
     LAUNCHCHK("gf_init_kernel");
 
@@ -1181,9 +1253,15 @@ struct GfEngine : Engine {
                            ra.as<double>(), qa.as<double>(), xhat.as<uint8_t>(), fs.frozen);
       LAUNCHCHK("gf vn kernel");
       prof_end(st);
-      const int synd_per = (int)std::max<size_t>(GF_SYND_WAVES, std::min<size_t>(64, (size_t)m * Fpad / (64 * 1024)));
-      hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)((Fpad + 63) / 64), (unsigned)((m + synd_per - 1) / synd_per)), dim3(64 * GF_SYND_WAVES), 0, st, gg,
-                         xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen, synd_per);
+      if (Q <= 16 && Fpad % 4 == 0) {
+        const int synd_per = (int)std::max<size_t>(GF_SYND_WAVES, std::min<size_t>(64, (size_t)m * Fpad / (256 * 1024)));
+        hipLaunchKernelGGL(gf_synd4_kernel, dim3((unsigned)((Fpad + 255) / 256), (unsigned)((m + synd_per - 1) / synd_per)), dim3(64 * GF_SYND_WAVES), 0, st, gg,
+                           xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen, synd_per);
+      } else {
+        const int synd_per = (int)std::max<size_t>(GF_SYND_WAVES, std::min<size_t>(64, (size_t)m * Fpad / (64 * 1024)));
+        hipLaunchKernelGGL(gf_synd_kernel, dim3((unsigned)((Fpad + 63) / 64), (unsigned)((m + synd_per - 1) / synd_per)), dim3(64 * GF_SYND_WAVES), 0, st, gg,
+                           xhat.as<uint8_t>(), sy, zhat.as<uint8_t>(), fs.dist, fs.frozen, synd_per);
+      }
       LAUNCHCHK("gf_synd_kernel");
       hipLaunchKernelGGL(gf_state_kernel, dim3((Fpad + 255) / 256), dim3(256), 0, st, fs, Fpad, t, WHT ? 1 : 0,
                          remaining.as<int32_t>() + t);
