@@ -751,7 +751,8 @@ __device__ __forceinline__ int tabc_mag(const unsigned char *t, unsigned i) {
 // LAST row again, is masked out of the sums, and stores that row's (correct) output a second time.
 //   dc <= CH:  one chunk; log tanh of every input is looked up once and kept, with the sign in bit 31
 //   dc >  CH:  (CH <= 16 only) two sweeps over the rows in double-buffered chunks, rows read twice
-template <int CH, int NT>
+//   ONE:       the host guarantees row weights <= CH (the chunked path, and its registers, are not built)
+template <int CH, int NT, bool ONE = false>
 __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
     Graph g, int nslab, int wps, MT<int>::vec *__restrict__ msg, const uint8_t *__restrict__ hard,
     const uint8_t *__restrict__ synd, uint32_t *__restrict__ fail, const uint32_t *__restrict__ image) {
@@ -808,6 +809,9 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
           sg[v] ^= (int)((unsigned)xv & m);
           if (decltype(pack)::value) x[c][v] = (int)(((unsigned)xv & 0x80000000u) | (unsigned)l);
         }
+        // (four rows' lookups in flight at a time: without the fence the scheduler interleaves all CH rows
+        // and needs ~220 registers, i.e. 8 waves per CU)
+        if (CH > 4 && (c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     };
     auto store = [&](int k0, int c, vec o) {
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
       rows[(size_t)k * 64] = o;
     };
 
-    if (dc <= CH) {
+    if (ONE || dc <= CH) {
       vec x[CH];
       unsigned hb[CH];
       load(0, x, hb, true);
@@ -832,8 +836,9 @@ __global__ __launch_bounds__(NT) void cn_tab_lds_kernel(
           o[v] = (tout ^ s) - s;
         }
         store(0, c, o);
+        if (CH > 4 && (c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-    } else if constexpr (CH <= 16) {
+    } else if constexpr (CH <= 16 && !ONE) {
       vec xa[CH], xb[CH];
       unsigned ha[CH], hbb[CH];
       load(0, xa, ha, true);

@@ -313,6 +313,8 @@ struct BinaryEngine : Engine {
 #define TAB_ATTR(RB, NT) HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<RB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes))
 #define TAB_ATTR3(RB) TAB_ATTR(RB, 512); TAB_ATTR(RB, 1024)
           TAB_ATTR3(8); TAB_ATTR(16, 512); TAB_ATTR3(4);
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<8, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
+          HIPCHK(hipFuncSetAttribute((const void *)cn_tab_lds_kernel<8, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTabcBytes));
 #undef TAB_ATTR3
 #undef TAB_ATTR
         }
@@ -379,10 +381,12 @@ struct BinaryEngine : Engine {
         // rows of a check in registers at a time / waves per CU (tools/probes/tab_sweep.sh, PEG-16000 Gbit/s):
         // 4 / 16: 6.88, 8 / 8: 6.50, 4 / 8: 6.52, 16 / 8: 5.21, whole checks of 32 rows / 8: 5.30, 8 / 16 (spills): 5.30
         // -- the double-buffered chunks overlap the row loads with the lookups, a whole check in registers does
-        // not.  Row weights <= 8 (DVB-S2): one chunk of eight holds the check and keeps its log tanh values.
+        // not.  Row weights <= 8 (DVB-S2): one chunk of eight holds the check and keeps its log tanh values; built
+        // without the chunked path and with the scheduler fenced every four rows it fits 16 waves per CU
+        // (DVB-S2 0.5: 2.82 -> 3.09 Gbit/s).
         int ch = rmax <= 8 ? 8 : 4;
         if (tab_rb == 4 || tab_rb == 8 || tab_rb == 16) ch = tab_rb;
-        int nt = ch == 4 ? 1024 : 512;
+        int nt = (ch == 4 || rmax <= 8) ? 1024 : 512;   // (the single-chunk build for row weights <= 8 needs 103 registers)
         if (tab_nt > 0 && ch <= 8) nt = tab_nt;
         const int wpb = nt / 64;
         const int wps = balanced_wps(nslab, (long)num_cu * wpb * oversub);
@@ -394,6 +398,12 @@ struct BinaryEngine : Engine {
 #define TAB_LAUNCH3(RB) do { if (nt == 512) TAB_LAUNCH(RB, 512); else TAB_LAUNCH(RB, 1024); } while (0)
         if (ch == 16) TAB_LAUNCH(16, 512);
         else if (ch == 4) TAB_LAUNCH3(4);
+        else if (rmax <= 8 && nt == 1024)
+          hipLaunchKernelGGL((cn_tab_lds_kernel<8, 1024, true>), grid, block, kTabcBytes, st, g, nslab, wps, msg.as<vec>(),
+                             hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab_c.as<uint32_t>());
+        else if (rmax <= 8)
+          hipLaunchKernelGGL((cn_tab_lds_kernel<8, 512, true>), grid, block, kTabcBytes, st, g, nslab, wps, msg.as<vec>(),
+                             hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab_c.as<uint32_t>());
         else TAB_LAUNCH3(8);
 #undef TAB_LAUNCH3
 #undef TAB_LAUNCH
