@@ -612,10 +612,17 @@ __global__ __launch_bounds__(256) void cn_single_read_kernel(
   if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
 }
 
+// (the 16-row sum-product instantiations ask for four waves per SIMD: left alone, the scheduler spreads the
+// long function bodies over 163-230 registers, two or three waves; asked, it needs 126-128 -- 1057.244 SPA_F32
+// 4.65 -> 5.78 Gbit/s, Frolov 2.51 -> 3.17, binary64 +4-6 %.  The 8-row ones are left alone: DVB-S2 unchanged,
+// (204,102) 4-5 % slower with the attribute)
+#ifndef LDPC_CN_REG_WAVES
+#define LDPC_CN_REG_WAVES __attribute__((amdgpu_waves_per_eu((ALG == ALG_SPA && RB >= 16) ? 4 : 1)))
+#endif
 // Register-resident variant for row weights <= RB: the whole check lives in
 // VGPRs between the load and the store (no LDS, no second read).
 template <typename T, int ALG, int RB>
-__global__ __launch_bounds__(256) void cn_reg_kernel(
+__global__ __launch_bounds__(256) LDPC_CN_REG_WAVES void cn_reg_kernel(
     Graph g, int nslab, typename MT<T>::vec *__restrict__ msg,
     const uint8_t *__restrict__ hard, const uint8_t *__restrict__ synd,
     uint32_t *__restrict__ fail, Tables tab) {
