@@ -85,6 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--save-counters", default=None,
                     help="write the live counter passes to this JSON (the committed fallback, profiles/r02_counters.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle spot-check of the last timed step")
+    ap.add_argument("--verify-frames", type=int, default=32)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short legs on BASELINE.json's other configs (reported under 'configs')")
+    ap.add_argument("--config-child", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -139,7 +144,7 @@ PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
                       "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"]))
 
 
-def live_counters(args, kernel_substr):
+def live_counters(args, kernel_substr, child=None, passes=None):
     """One rocprofv3 --pmc pass per counter group over `bench.py --pmc-child` (the same
     workload, one launch), as children of this process before it touches the GPU.
     -> {counter: value per launch} or None."""
@@ -149,11 +154,12 @@ def live_counters(args, kernel_substr):
     out = {}
     base = tempfile.mkdtemp(prefix="ldpc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--gpus", "1", "--steps", "1", "--warmup", "0",
-             "--frames", str(args.frames), "--alg", args.alg, "--iters", str(args.iters), "--p", str(args.p),
-             "--code", args.code, "--early-exit", str(args.early_exit), "--cn-variant", str(args.cn_variant)]
+    if child is None:
+        child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--gpus", "1", "--steps", "1", "--warmup", "0",
+                 "--frames", str(args.frames), "--alg", args.alg, "--iters", str(args.iters), "--p", str(args.p),
+                 "--code", args.code, "--early-exit", str(args.early_exit), "--cn-variant", str(args.cn_variant)]
     try:
-        for tag, counters in PMC_PASSES:
+        for tag, counters in (passes or PMC_PASSES):
             d = os.path.join(base, tag)
             cmd = [exe, "--pmc"] + counters + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + child
             try:
@@ -260,11 +266,168 @@ def cpu_baseline(args, K_info):
     multi = sum(K_info * f / t for f, t in res) / 1e9
     frames = sum(f for f, _ in res)
     return {"value": round(multi, 6), "unit": "Gbit/s", "cores": P, "kind": "port", "cpu_model": cpu_model(),
+            "note": "the port keeps the reference's O(dc^2) check node but walks index tables where the reference chases "
+                    "pointer tables; the reference's own dec() (a mex source, not buildable here without stand-in headers) "
+                    "was probed by the survey at 0.41 Mbit/s per Xeon core on this workload (BASELINE.md): the port is "
+                    "about 4x kinder to the CPU than the reference, so GPU/CPU ratios against it understate the reference's gap",
             "one_core": {"value": round(one, 6), "frames": f1, "seconds": round(t1, 2)},
             "sample": f"{frames} frames of the same workload through oracle/ldpc_oracle.c (restatement of the "
                       f"reference dec(), gcc -O2), {P} single-threaded processes side by side for "
                       f"{args.cpu_seconds * 0.6:.0f} s each ({wall:.1f} s wall incl. start-up); one_core: {f1} frames, "
                       f"one process alone"}
+
+
+# ------------------------------------------------ oracle spot-check (checker)
+
+def verify_frames(code_path, alg, llr_t, bits_t, iters_t, status_t, max_iter, nver):
+    """The CPU oracle as the CHECKER of what was just timed (never as the thing measured): `nver`
+    frames spread over the last step's batch -- the first, the last, evenly in between -- are
+    copied to the host with the decoder's outputs and decoded again by oracle/ldpc_oracle.c
+    (ora_dec_minsum_fixed / ora_dec_minsum_f32 / ora_dec_minsum); decoded bits, iteration count
+    and status must be equal.  -> (frames checked, frames that differ)."""
+    import torch
+    from oracle.bindings import Oracle
+    F = int(llr_t.shape[0])
+    idx = sorted(set(np.linspace(0, F - 1, min(nver, F)).astype(np.int64).tolist()))
+    sel = torch.tensor(idx, device=llr_t.device)
+    llr = llr_t[sel].cpu().numpy()
+    bits = bits_t[sel].cpu().numpy()
+    iters = iters_t[sel].cpu().numpy()
+    status = status_t[sel].cpu().numpy()
+    ora = Oracle()
+    oc = ora.load(code_path)
+    s = np.zeros(oc.m, np.int32)
+    bad = 0
+    for k in range(len(idx)):
+        if alg == "q88":
+            r = ora.dec_minsum_fixed(oc, llr[k].astype(np.float64) / 256.0, s, max_iter, None, oc.m + 1)
+        elif alg == "f32":
+            r = ora.dec_minsum_f32(oc, llr[k], s, max_iter)
+        else:
+            r = ora.dec_minsum(oc, llr[k], s, max_iter)
+        same = r["rc"] == status[k] and r["iters"] == iters[k] and np.array_equal(r["bits"], bits[k])
+        bad += 0 if same else 1
+    return len(idx), bad
+
+
+# ------------------------------------------- the other configs of BASELINE.json
+
+CODES_DIR = os.path.join(ROOT, "tests", "golden", "codes")
+# Short legs, one per remaining config, run after the headline (N = 1 only): the device Monte-Carlo
+# loop (source, enc(), channel, dec(), classification on the GPU) for the binary ones, resident
+# random priors for GF(4).  "fused": the frame-resident kernels (vector-issue bound, instruction
+# count from one live rocprofv3 pass over `--config-child i`); the others are two-pass (HBM bound,
+# algorithmic bytes per launch over the launch time).
+CONFIG_LEGS = [
+    dict(id="configs[0]", code="204.33.484.txt", alg="MINSUM_F64", dt="F64", channel="AWGN", ebn0=2.0, iters=50,
+         frames=1 << 20, batch=1 << 18, fused=True, b=8,
+         what="MacKay (204,102) min-sum in the reference's binary64, BPSK/AWGN Eb/N0 = 2 dB, <= 50 iterations, early exit"),
+    dict(id="configs[2]/SPA_F64", code="dvb_H_0.5.txt", alg="SPA_F64", dt="F64", channel="AWGN", ebn0=1.0, iters=50,
+         frames=4096, batch=4096, fused=False, b=8,
+         what="DVB-S2 rate 1/2 (n = 64800) sum-product in the reference's binary64, Eb/N0 = 1.0 dB, <= 50 iterations, early exit"),
+    dict(id="configs[2]/SPA_TABLE_Q14", code="dvb_H_0.5.txt", alg="SPA_TABLE_Q14", dt="I32", channel="AWGN", ebn0=1.0,
+         iters=50, frames=4096, batch=4096, fused=False, b=4,
+         what="DVB-S2 rate 1/2 table sum-product (test_code_B), Eb/N0 = 1.0 dB, <= 50 iterations, early exit"),
+    dict(id="configs[3]", code="32000.2240.3.105.txt", alg="MINSUM_Q88", dt="I16", channel="BSC_EXACT", p=13.0 / 32000,
+         iters=200, frames=1 << 16, batch=1 << 16, fused=True, b=2,
+         what="32000.2240.3.105 Q8.8 min-sum, exactly 13 flips per frame (FER floor region), <= 200 iterations, syndrome early exit"),
+    dict(id="configs[4]", code="q4.sp.9000.6000.4500.1", alg="GF2P_WHT", dt="I32", channel=None, iters=10, frames=2048,
+         batch=2048, fused=False, b=4,
+         what="GF(4) q4.sp.9000.6000.4500.1 Walsh-Hadamard check nodes, 10 iterations executed, random priors resident"),
+]
+
+
+def run_config_leg(i, local_rank, child=False):
+    """One leg of CONFIG_LEGS on this rank's GPU -> its record (child: one untimed run for the profiler)."""
+    import torch
+    import ldpc_amd
+    from ldpc_amd import ALG, CH, DT
+    from ldpc_amd.sweep import ebn0_to_sigma
+    leg = CONFIG_LEGS[i]
+    code = ldpc_amd.Code.from_alist(os.path.join(CODES_DIR, leg["code"]))
+    n, m, E, q = code.n, code.m, code.E, code.q
+    frames = leg["frames"] if not child else min(leg["frames"], leg["batch"])
+    dec = ldpc_amd.Decoder(code, getattr(ALG, leg["alg"]), device=local_rank, max_frames=leg["batch"],
+                           early_exit=leg["channel"] is not None)
+    dt = getattr(DT, leg["dt"])
+    rec = {"config": leg["id"], "workload": leg["what"], "alg": leg["alg"], "frames": frames, "iterations": leg["iters"]}
+    if leg["channel"] is None:                              # GF(4): resident random priors, all iterations executed
+        dev = torch.device("cuda", local_rank)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(3)
+        u = torch.rand((frames, n, q), device=dev, generator=gen)
+        llr = (torch.log2(u / u.sum(dim=2, keepdim=True)) * 16384).to(torch.int32).contiguous()
+        bits = torch.empty((frames, n), dtype=torch.uint8, device=dev)
+        status = torch.empty(frames, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            dec.decode_device(frames, llr.data_ptr(), dt, leg["iters"], None, bits.data_ptr(), None, None,
+                              status.data_ptr(), None, st)
+            torch.cuda.synchronize()
+            return None
+        info_bits = (n - m) * math.log2(q)
+    else:
+        mc = ldpc_amd.MonteCarlo(code, dec, device=local_rank)
+        par = ebn0_to_sigma(leg["ebn0"], (n - m) / n) if leg["channel"] == "AWGN" else leg["p"]
+
+        def run():
+            return mc.run(frames, getattr(CH, leg["channel"]), par, dt, leg["iters"], seed=SEED)
+        info_bits = n - m
+    run()                                                   # warm-up (first launches, lazy allocations)
+    if child:
+        return None
+    dec.profile(True)
+    t0 = time.perf_counter()
+    cnt = run()
+    sec = time.perf_counter() - t0
+    ms_k, cnt_k = dec.profile_read()
+    fl_k = dec.profile_frames()
+    dec.profile(False)
+    rec.update({"value": round(info_bits * frames / sec / 1e9, 4), "unit": "Gbit/s", "seconds": round(sec, 4),
+                "Msymbols_per_s": round(n * frames / sec / 1e6, 1)})
+    if cnt is not None:
+        rec.update({"fer": round(cnt["not_converged"] / max(1, cnt["frames"]), 6), "undetected": cnt["undetected"],
+                    "avg_iterations": round(cnt["iterations"] / max(1, cnt["frames"]), 3),
+                    "includes": "source, enc(), channel, dec() and classification, all on the device"})
+    names = ["variable pass", "check pass", "frame-resident whole-decode kernel", "other"]
+    if cnt_k.sum() > 0:
+        k = int(np.argmax(ms_k))
+        avg_ms = float(ms_k[k]) / max(1, int(cnt_k[k]))
+        b = leg["b"] * (q if q > 2 else 1)
+        rec["kernel"] = names[k]
+        rec["kernel_ms"] = {names[j]: round(float(ms_k[j]), 3) for j in range(4) if cnt_k[j]}
+        if k in (0, 1):
+            # bytes of every launch of the class: each launch priced by the frames it worked on
+            # (ldpc_decoder_profile_frames: the second stage of a two-stage early exit holds fewer)
+            byt = ((2 * E * b + n * b) if k == 0 else 2 * E * b) * int(fl_k[k])
+            ach = byt / (float(ms_k[k]) * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
+                               "launches": int(cnt_k[k]), "algorithmic_bytes_per_launch": byt // max(1, int(cnt_k[k])),
+                               "traffic": None,
+                               "figure": "SURVEY 8(d) bytes of that pass x the frames each launch worked on, summed over "
+                                         "the launches / their summed time"}
+        else:
+            rec["roofline"] = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                               "frac": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt_k[k]), "traffic": None}
+    return rec
+
+
+CONFIG_PMC_PASS = (("sq", ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]),)
+
+
+def config_counters(args):
+    """Live vector-instruction counts of the legs whose dominant kernel is frame-resident:
+    one rocprofv3 pass each over `bench.py --config-child i` (before the parent touches the GPU)."""
+    out = {}
+    for i, leg in enumerate(CONFIG_LEGS):
+        if not leg["fused"]:
+            continue
+        child = [sys.executable, os.path.abspath(__file__), "--config-child", str(i)]
+        c, src = live_counters(args, "fused_", child=child, passes=CONFIG_PMC_PASS)
+        out[i] = (c, src)
+    return out
 
 
 # --------------------------------------------------------------------- main
@@ -315,12 +478,15 @@ def main():
     if args.dry:
         dry_run(args, rank, world)
         return
+    if args.config_child >= 0:
+        run_config_leg(args.config_child, local_rank, child=True)
+        return
 
     b_msg = {"q88": 2, "f32": 4, "f64": 8}[args.alg]
     fused_possible = args.cn_variant == 0 and os.environ.get("LDPC_HIP_FUSED", "1") != "0"
 
     # Legs that start child processes come first: nothing here has touched the GPU yet.
-    counters, counters_src, cpu = None, None, None
+    counters, counters_src, cpu, cfg_counters = None, None, None, {}
     if rank == 0 and world == 1 and not args.pmc_child:
         if not args.no_pmc:
             counters, counters_src = live_counters(args, "fused_" if fused_possible else "cn_")
@@ -334,6 +500,8 @@ def main():
         if not args.no_cpu:
             code_n_m = np.loadtxt(args.code, max_rows=1, dtype=int)
             cpu = cpu_baseline(args, int(code_n_m[0] - code_n_m[1]))
+        if not args.no_configs and not args.no_pmc:
+            cfg_counters = config_counters(args)
     elif rank == 0 and not args.pmc_child:
         # N > 1: no child processes beside the ranks; the instruction count per launch is the
         # committed one-GPU pass of the same workload (every rank runs that same launch)
@@ -414,6 +582,15 @@ def main():
     if args.pmc_child:
         return
 
+    # the oracle as the checker of the last timed step (rank 0): a number whose frames differ from
+    # the reference's results is no number
+    verified = None
+    if rank == 0 and not args.no_verify:
+        nv, bad = verify_frames(args.code, args.alg, llr, bits, iters, status, args.iters, args.verify_frames)
+        if bad:
+            raise SystemExit(f"bench.py: {bad} of {nv} frames of the last timed step differ from the CPU oracle")
+        verified = nv
+
     # the path's only collective: error counters (and the max of the elapsed time)
     fails = int((status != 0).sum().item())
     undet = int(((status == 0) & (bits.any(dim=1))).sum().item())
@@ -448,6 +625,13 @@ def main():
             step2()
         fence()
         el2 = time.perf_counter() - t0
+        v2 = None
+        if rank == 0 and not args.no_verify:
+            nv, bad = verify_frames(args.code, "f64", llr2, bits[:sF], iters[:sF], status[:sF], args.iters,
+                                    max(4, args.verify_frames // 2))
+            if bad:
+                raise SystemExit(f"bench.py: {bad} of {nv} frames of the MINSUM_F64 leg differ from the CPU oracle")
+            v2 = nv
         if use_dist:
             t = torch.tensor([el2], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,8 +639,34 @@ def main():
         secondary = {"alg": "MINSUM_F64 (the reference's double min-sum, test_code_min_sum_B.c:137-208, bit-exact)",
                      "value": round(K_info * sF * s_steps * world / el2 / 1e9, 3), "unit": "Gbit/s",
                      "frames_per_step_per_gpu": sF, "steps": s_steps, "ms_per_step": round(el2 / s_steps * 1e3, 3),
-                     "dtype": "f64", "avg_iterations": round(float(iters[:sF].float().mean().item()), 3)}
+                     "dtype": "f64", "avg_iterations": round(float(iters[:sF].float().mean().item()), 3),
+                     "verified_frames": v2}
         del dec2, llr2
+
+    # BASELINE.json's other configs, a short leg each (one GPU; the scaling runs time the headline only)
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        if "dec" in dir():
+            del dec
+        del llr, bits
+        torch.cuda.empty_cache()
+        configs = []
+        for i in range(len(CONFIG_LEGS)):
+            try:
+                rec = run_config_leg(i, local_rank)
+            except Exception as e:                         # a leg that fails must not take the headline with it
+                rec = {"config": CONFIG_LEGS[i]["id"], "error": f"{type(e).__name__}: {e}"}
+            c, src = cfg_counters.get(i, (None, None))
+            rl = rec.get("roofline")
+            if rl and rl["bound"] == "valu":
+                rl["counters"] = src
+                if c and c.get("SQ_INSTS_VALU"):
+                    ach = c["SQ_INSTS_VALU"] / (rl["avg_launch_ms"] * 1e-3) / 1e9
+                    rl.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4),
+                               "valu_wave_instructions_per_launch": int(c["SQ_INSTS_VALU"])})
+                    if c.get("SQ_WAVE_CYCLES"):
+                        rl["wait_any_share"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+            configs.append(rec)
 
     if rank == 0:
         total_frames = F * args.steps * world
@@ -519,8 +729,9 @@ def main():
                        "ranks": world},
             "avg_iterations": round(avg_it, 3), "frame_failures": fails, "undetected": undet,
             "hbm_equivalent_GBps_per_gpu": round(whole, 1),
+            "verified_frames": verified,
             "roofline": roofline, "cpu_baseline": cpu,
-            "secondary": secondary,
+            "secondary": secondary, "configs": configs,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -175,18 +175,31 @@ int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void *llr, int 
 /* ldpc_decode_batch_device() for callers that cannot allocate device memory -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
  * counterpart in the reference (whose dec() works in file-scope host arrays).  Same arguments,
- * same results; but every byte of device scratch the call needs -- the frame-queue head of
- * the frame-resident decoders; the edge-message store, hard decisions and per-frame state of
- * the two-pass decoders -- comes from one file-scope `static __device__` array of
- * 32 MiB that each GPU the library runs on holds until the process ends (its per-device
- * address is resolved once, in ldpc_decoder_create()).  The call makes no hipMalloc /
- * hipFree / allocating library call.  Binary algorithms only.  Limits, refused with
- * LDPC_ERR_ARG and a message naming the figure: the two-pass decoders need
- * 64 * ceil(nframes / SF) * (16 n + 16 E + n + 2 m + ...) bytes (SF = 512 frames for int16
- * messages, 256 for binary32 / int32, 128 for binary64), which must fit the 32 MiB; their
- * max_iter is at most 254; per-kernel timing (ldpc_decoder_profile) is off inside the call.
- * All calls on one GPU share that GPU's array: the call clears what must start at zero, and
- * two calls that overlap on one GPU (two decoders, two streams, two host threads) race. */
+ * same results; but every byte of device scratch the call needs comes from one file-scope
+ * `static __device__` array of 32 MiB that each GPU the library runs on holds until the
+ * process ends (its per-device address is resolved once, in ldpc_decoder_create()).  The call
+ * makes no hipMalloc / hipFree / allocating library call.  Binary algorithms only.
+ * What comes out of the array, per decoder:
+ *   frame-resident Q8.8 / float min-sum:  the frame-queue head (4 bytes); the binary64 decoder on
+ *     codes whose channel LLRs do not fit LDS beside the sums (PEG-16000) also keeps one placed
+ *     copy of q0 per workgroup there, n * 8 bytes each: min(nframes, workgroups) of them must fit;
+ *   staircase Q8.8 (DVB-S2 long frames):  the queue head plus 10 bytes per check and workgroup
+ *     (channel values of the staircase variables, two sets of minima rows: 320 KiB per workgroup
+ *     for dvb_H_0.5) -- the grid is CAPPED at the workgroups whose rows fit (102 of 256 for that
+ *     code), so throughput is below ldpc_decode_batch_device()'s there; results are the same;
+ *   two-pass decoders:  edge-message store, hard decisions and per-frame state,
+ *     64 * ceil(nframes / SF) * (16 n + 16 E + n + 2 m + ...) bytes (SF = 512 frames for int16
+ *     messages, 256 for binary32 / int32, 128 for binary64), which must fit the 32 MiB; their
+ *     max_iter is at most 254 and they never take the second stage of the two-stage early exit.
+ * A size beyond these limits is refused with LDPC_ERR_ARG and a message naming the figure.
+ * Per-kernel timing (ldpc_decoder_profile, LDPC_HIP_FUSED_TIMING) is off inside the call.
+ * All calls on one GPU share that GPU's array; the call clears what must start at zero.  Calls on
+ * one GPU must therefore not overlap, and the library refuses (LDPC_ERR_ARG) the overlaps it can
+ * see: a call that arrives while another is inside the library (two host threads, two decoders),
+ * and a call on a stream other than the previous call's while that call's kernels are still
+ * running (checked with an event recorded at the end of every call outside graph capture).
+ * Successive calls on ONE stream are ordered by the stream and always served.  Work replayed from
+ * a captured graph is invisible to these checks: ordering graph launches is the caller's. */
 int ldpc_decode_batch_device_noalloc(ldpc_decoder *d, int nframes, const void *llr, int llr_dtype,
                                      const uint8_t *syndrome, int max_iter,
                                      uint8_t *bits_out, int32_t *iters_out, uint8_t *synd_out,
@@ -250,6 +263,11 @@ int64_t ldpc_spa_tables_selfcheck(int64_t *stats);
  * whole-decode kernel, 3 other. */
 int ldpc_decoder_profile(ldpc_decoder *d, int enable);
 int ldpc_decoder_profile_read(ldpc_decoder *d, double *ms, int32_t *launches);
+/* Companion of ldpc_decoder_profile_read() (no counterpart in the reference): per kernel class, the sum
+ * over the launches that read covered of the frames each launch worked on (the second stage of a
+ * two-stage early exit launches on fewer frames than the first), so that a benchmark can price a
+ * class's launches by the bytes they really had to move.  frame_launches[4]. */
+int ldpc_decoder_profile_frames(ldpc_decoder *d, int64_t *frame_launches);
 
 /* ------------------------------------------------ Monte-Carlo loop on the device
  * The trial loop of the reference's *_cw_noise_gen harnesses

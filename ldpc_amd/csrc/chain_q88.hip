@@ -526,6 +526,18 @@ struct ChainQ88Engine : Engine {
         const int ca = check_of(e0), cb = check_of(e1);
         if (std::min(ca, cb) == j && std::max(ca, cb) == j + 1) { right[j] = v; is_chain[v] = 1; break; }
       }
+    // No staircase, no point: without weight-2 variables between consecutive checks this kernel is one
+    // workgroup of m / R threads per CU walking LDS sums only, which the two-pass engine beats.  At least
+    // half of the checks must hand a variable to their successor (DVB-S2: all but the last).
+    {
+      int nstairs = 0;
+      for (int j = 0; j < m; j++) nstairs += right[j] >= 0;
+      if (2 * nstairs < m) {
+        ldpc_set_error("staircase Q8.8 decoder: the code has no staircase (" + std::to_string(nstairs) + " of " +
+                       std::to_string(m) + " checks share a weight-2 variable with the next check)");
+        return LDPC_ERR_UNSUPPORTED;
+      }
+    }
     // a check without a right staircase variable may park one weight-1 variable there instead
     // ("private": posterior = q0 + the check's own message; DVB-S2's last parity bit)
     std::vector<char> priv(m, 0);
@@ -654,12 +666,14 @@ struct ChainQ88Engine : Engine {
     a.counter = counter;
     a.words = words; a.dummy_base = dummy_base;
     a.timing = nullptr;
-    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;
+    // (cycle counters of timing builds: they allocate and synchronise, so never inside the allocation-free call)
+    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr && counter == d_counter.as<int>();
     if (timing) {
       if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
       HIPCHK(hipMemsetAsync(d_timing.p, 0, 16 * 8 * sizeof(unsigned long long), st));
       a.timing = d_timing.as<unsigned long long>();
     }
+    prof_cur_frames = nframes;
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
     LAUNCHCHK("chain_q88_kernel");

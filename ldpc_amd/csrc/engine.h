@@ -102,8 +102,10 @@ struct Engine {
   // Optional per-kernel timing (bench.py's roofline leg): hipEvent pairs around the
   // launches of each kernel class, read back with profile_read().
   enum { K_VN = 0, K_CN = 1, K_FUSED = 2, K_OTHER = 3, K_KINDS = 4 };
-  struct ProfRec { int kind; hipEvent_t a, b; };
+  struct ProfRec { int kind; hipEvent_t a, b; int frames; };
   bool profiling = false;
+  int prof_cur_frames = 0;            // frames the launches being recorded work on (set by decode())
+  long long prof_frames[4] = {};      // per kind: sum over the launches of the last profile_read() of those frames
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
   hipEvent_t prof_event() {
@@ -114,7 +116,7 @@ struct Engine {
   }
   void prof_begin(int kind, hipStream_t st) {
     if (!profiling) return;
-    ProfRec r{kind, prof_event(), prof_event()};
+    ProfRec r{kind, prof_event(), prof_event(), prof_cur_frames};
     (void)hipEventRecord(r.a, st);
     prof_recs.push_back(r);
   }
@@ -124,11 +126,11 @@ struct Engine {
   }
   // sums elapsed ms and launch counts per kind since the last read; synchronises
   void profile_read(double ms[K_KINDS], int count[K_KINDS]) {
-    for (int k = 0; k < K_KINDS; k++) { ms[k] = 0; count[k] = 0; }
+    for (int k = 0; k < K_KINDS; k++) { ms[k] = 0; count[k] = 0; prof_frames[k] = 0; }
     for (auto &r : prof_recs) {
       (void)hipEventSynchronize(r.b);
       float t = 0;
-      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kind] += t; count[r.kind]++; }
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kind] += t; count[r.kind]++; prof_frames[r.kind] += r.frames; }
       prof_pool.push_back(r.a);
       prof_pool.push_back(r.b);
     }

@@ -922,6 +922,7 @@ struct FusedFloatEngine : Engine {
     if (grid > nframes) grid = nframes;
     a.chunk = (int)std::max<long>(1, std::min<long>(std::min<long>(4096 / n, nframes / (grid * 16)), 16));
     if (const char *e = getenv("LDPC_HIP_FUSED_CHUNK")) a.chunk = std::max(1, atoi(e));
+    prof_cur_frames = nframes;
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
     LAUNCHCHK("fused_ms_kernel");

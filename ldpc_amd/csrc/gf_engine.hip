@@ -1125,6 +1125,7 @@ struct GfEngine : Engine {
              int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
              hipStream_t st) override {
     if (nframes <= 0) return LDPC_OK;
+    prof_cur_frames = nframes;
     if (llr_out) {
       ldpc_set_error("llr_out is not available for the non-binary algorithms");
       return LDPC_ERR_ARG;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -537,6 +538,7 @@ struct BinaryEngine : Engine {
     const bool early = opts.early_exit != 0;
     int rc;
     if ((rc = ensure_remaining(max_iter + 2))) return rc;
+    prof_cur_frames = nframes;
 
     hipLaunchKernelGGL(init_state_kernel, dim3((nslab * 64 + 255) / 256), dim3(256), 0, st, nslab, V,
                        nframes, fail.as<uint32_t>(), done.as<uint8_t>(), iters.as<int32_t>());
@@ -1008,6 +1010,7 @@ struct FusedQ88Engine : Engine {
     int *counter = ws_counter ? ws_counter : d_counter.as<int>();
     HIPCHK(hipMemsetAsync(counter, 0, 4, st));
     if (sout) HIPCHK(hipMemsetAsync(sout, 0, (size_t)nframes * m, st));
+    prof_cur_frames = nframes;
     FusedArgs a;
     a.colT = d_colT.as<uint16_t>();
     a.dcT = d_dcT.as<uint8_t>();
@@ -1021,7 +1024,8 @@ struct FusedQ88Engine : Engine {
     a.words = sched.words; a.dummy_base = sched.dummy_base; a.ndummy = sched.ndummy;
     a.timing = nullptr;
     a.layered = layered ? 1 : 0;
-    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr;   // (only timing builds of the kernel write it)
+    // (only timing builds of the kernel write it; it allocates and synchronises, so never inside the allocation-free call)
+    const bool timing = getenv("LDPC_HIP_FUSED_TIMING") != nullptr && !ws_counter;
     if (timing) {
       if (int rc = d_timing.ensure(16 * 8 * sizeof(unsigned long long))) return rc;
       HIPCHK(hipMemsetAsync(d_timing.p, 0, 16 * 8 * sizeof(unsigned long long), st));
@@ -1077,6 +1081,17 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 void *g_scratch_ptr[MAX_DEVICES] = {};
+// One call at a time per GPU: every call on a device works in that device's one array.  `busy` is a
+// try-lock held while a call is on the host; `last_ev` (created at set-up, not in the call) marks the
+// end of the previous call's work on the device, so that a call on ANOTHER stream while that work is
+// still running is refused instead of racing with it (the same stream orders itself).
+struct ScratchUse {
+  std::atomic<bool> busy{false};
+  hipEvent_t last_ev = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+};
+ScratchUse g_scratch_use[MAX_DEVICES];
 
 // Address of `scratch` on `device` (which must be the current device); resolved once per device.
 int scratch_on_device(int device, void **out) {
@@ -1086,6 +1101,7 @@ int scratch_on_device(int device, void **out) {
     void *p = nullptr;
     HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) { ldpc_set_error("hipGetSymbolAddress(scratch) returned null"); return LDPC_ERR_HIP; }
+    HIPCHK(hipEventCreateWithFlags(&g_scratch_use[device].last_ev, hipEventDisableTiming));
     g_scratch_ptr[device] = p;
   }
   *out = g_scratch_ptr[device];
@@ -1181,11 +1197,14 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
         const int cmode = ce ? atoi(ce) : 1;
         if (opts->cn_variant == 0 && fmode != 0 && ((cmode == 1 && !fused) || cmode == 2)) {
           std::unique_ptr<Engine> ch(ldpc_make_chain_q88_engine());
-          if (ch && ch->init(d->code, d->opts) == LDPC_OK) {
+          const int crc = ch ? ch->init(d->code, d->opts) : LDPC_ERR_NOMEM;
+          if (crc == LDPC_OK) {
             d->eng = std::move(ch);
             *out = d.release();
             return LDPC_OK;
           }
+          // "not a code for this kernel" falls through to the other engines; anything else is an error
+          if (crc != LDPC_ERR_UNSUPPORTED) return crc;
         }
         if (fused) d->eng.reset(new FusedQ88Engine);
         // a weight-1 check sends +-200 (min over nothing, _fixed.c:270), which
@@ -1307,6 +1326,12 @@ extern "C" int ldpc_decoder_profile_read(ldpc_decoder *d, double *ms, int32_t *l
   return LDPC_OK;
 }
 
+extern "C" int ldpc_decoder_profile_frames(ldpc_decoder *d, int64_t *frame_launches) {
+  if (!d || !frame_launches) return LDPC_ERR_ARG;
+  for (int k = 0; k < Engine::K_KINDS; k++) frame_launches[k] = d->eng->prof_frames[k];
+  return LDPC_OK;
+}
+
 extern "C" int ldpc_decoder_max_frames(const ldpc_decoder *d) { return d ? d->max_frames : LDPC_ERR_ARG; }
 extern "C" int ldpc_decoder_last_iterations(const ldpc_decoder *d) {
   return d ? d->eng->last_iterations : LDPC_ERR_ARG;
@@ -1339,12 +1364,34 @@ extern "C" int ldpc_decode_batch_device_noalloc(ldpc_decoder *d, int nframes, co
   void *ws = nullptr;
   int rc = scratch_on_device(d->opts.device, &ws);   // resolved by ldpc_decoder_create(); a lookup here
   if (rc) return rc;
+  // one call at a time on this GPU's array
+  ScratchUse &use = g_scratch_use[d->opts.device];
+  if (use.busy.exchange(true, std::memory_order_acquire)) {
+    ldpc_set_error("allocation-free decode: another call is using this GPU's static scratch (calls on one GPU must not overlap)");
+    return LDPC_ERR_ARG;
+  }
+  struct Release { std::atomic<bool> &b; ~Release() { b.store(false, std::memory_order_release); } } release{use.busy};
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (use.have_last && use.last_stream != st && hipEventQuery(use.last_ev) == hipErrorNotReady) {
+    ldpc_set_error("allocation-free decode: the previous call's work on another stream of this GPU is still running "
+                   "in the static scratch (order the streams, or use ldpc_decode_batch_device)");
+    return LDPC_ERR_ARG;
+  }
+  (void)hipGetLastError();
   // (per-kernel timing creates events on demand: not inside this call)
   const bool prof = d->eng->profiling;
   d->eng->profiling = false;
   rc = d->eng->decode_ws(ws, LDPC_NOALLOC_SCRATCH_BYTES, nframes, llr, llr_dtype, syndrome, max_iter, bits_out,
-                         iters_out, synd_out, status_out, llr_out, (hipStream_t)stream);
+                         iters_out, synd_out, status_out, llr_out, st);
   d->eng->profiling = prof;
+  // where this call's work ends on the device (a stream under graph capture has no such point yet)
+  use.have_last = false;
+  if (cap == hipStreamCaptureStatusNone && hipEventRecord(use.last_ev, st) == hipSuccess) {
+    use.last_stream = st;
+    use.have_last = true;
+  }
   return rc;
 }
 

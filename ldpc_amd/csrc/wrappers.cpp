@@ -70,11 +70,33 @@ Rng take_rng() {   // one independent stream per entry-point call
 struct Cached {
   std::string file;
   int alg;
+  int frames;         // pass size the decoder was made for (part of the key: the single-frame harnesses keep a small one)
   ldpc_code *code;
   ldpc_decoder *dec;
   ldpc_mc *mc;        // device Monte-Carlo context (binary codes), made on first use
+  uint64_t used;      // tick of the last call that asked for it
 };
 std::vector<Cached> g_cache;
+uint64_t g_cache_tick = 0;
+// A cached decoder holds its workspace on the device (gigabytes for a Monte-Carlo pass of a two-pass
+// engine); a sweep over many codes and algorithms must not grow without bound.  At most
+// LDPC_HIP_CACHE_MAX (default 6) decoders stay; the least recently used goes first.  The entry
+// points are serialised (SERIALISED), so nothing but the caller's own decoder is in use.
+size_t cache_max() {
+  if (const char *e = getenv("LDPC_HIP_CACHE_MAX")) { const int v = atoi(e); if (v > 0) return (size_t)v; }
+  return 6;
+}
+void evict_lru_locked() {
+  while (g_cache.size() >= cache_max()) {
+    size_t old = 0;
+    for (size_t i = 1; i < g_cache.size(); i++)
+      if (g_cache[i].used < g_cache[old].used) old = i;
+    if (g_cache[old].mc) ldpc_mc_free(g_cache[old].mc);
+    ldpc_decoder_free(g_cache[old].dec);
+    ldpc_code_free(g_cache[old].code);
+    g_cache.erase(g_cache.begin() + (long)old);
+  }
+}
 
 // Frames per device pass of the Monte-Carlo harnesses: LDPC_HIP_MC_BATCH, else about 4 GB of
 // 8-byte edge messages' worth, between 1024 and 16384 frames in steps of 512 (binary codes; a
@@ -95,11 +117,14 @@ int cache_device() {
   return 0;
 }
 
-int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec, ldpc_mc **mc = nullptr) {
+// frames = 0: a Monte-Carlo pass (mc_batch); > 0: a decoder for that many frames per call (the
+// single-frame harnesses ask for 64, so that one frame does not reserve a Monte-Carlo pass's workspace)
+int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec, ldpc_mc **mc = nullptr, int frames = 0) {
   if (!file) return LDPC_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto &c : g_cache)
-    if (c.alg == alg && c.file == file) {
+    if (c.alg == alg && c.frames == frames && c.file == file) {
+      c.used = ++g_cache_tick;
       *code = c.code;
       *dec = c.dec;
       if (mc) {
@@ -111,6 +136,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
       }
       return LDPC_OK;
     }
+  evict_lru_locked();
   ldpc_code *c = nullptr;
   int rc = ldpc_code_load_alist(file, &c);
   if (rc) return rc;
@@ -118,7 +144,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
   memset(&o, 0, sizeof o);
   o.alg = alg;
   o.device = cache_device();
-  o.max_frames = mc_batch(c);
+  o.max_frames = frames > 0 ? frames : mc_batch(c);
   o.early_exit = 1;
   ldpc_decoder *d = nullptr;
   rc = ldpc_decoder_create(c, &o, &d);
@@ -136,7 +162,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
     }
     *mc = m;
   }
-  g_cache.push_back({file, alg, c, d, m});
+  g_cache.push_back({file, alg, frames, c, d, m, ++g_cache_tick});
   *code = c;
   *dec = d;
   return LDPC_OK;
@@ -206,7 +232,7 @@ int single_frame(const char *file, int alg, int iteration, const int *x, const i
   if (!x || !s || !q0 || iteration < 0) return LDPC_ERR_ARG;
   ldpc_code *code;
   ldpc_decoder *dec;
-  int rc = get_decoder(file, alg, &code, &dec);
+  int rc = get_decoder(file, alg, &code, &dec, nullptr, 64);
   if (rc) return rc;
   const int n = ldpc_code_n(code), m = ldpc_code_m(code);
   if (alg == LDPC_ALG_MINSUM_Q88) {

@@ -93,6 +93,7 @@ def load_library():
     L.ldpc_code_vpass_place_stats.argtypes = [vp, ip, vp]
     L.ldpc_decoder_profile.argtypes = [vp, ip]
     L.ldpc_decoder_profile_read.argtypes = [vp, vp, vp]
+    L.ldpc_decoder_profile_frames.argtypes = [vp, vp]
     L.ldpc_mc_create.argtypes = [vp, vp, ip, C.POINTER(vp)]
     L.ldpc_mc_free.argtypes = [vp]
     L.ldpc_mc_free.restype = None
@@ -298,6 +299,12 @@ class Decoder:
         cnt = np.zeros(4, np.int32)
         check(load_library().ldpc_decoder_profile_read(self._h, _ptr(ms), _ptr(cnt)))
         return ms, cnt
+
+    def profile_frames(self):
+        """-> frame_launches[4]: per kernel class, the frames summed over the launches of the last profile_read()."""
+        fl = np.zeros(4, np.int64)
+        check(load_library().ldpc_decoder_profile_frames(self._h, _ptr(fl)))
+        return fl
 
     @property
     def last_iterations(self):

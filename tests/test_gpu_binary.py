@@ -93,8 +93,12 @@ def test_minsum_f32(hip, oracle, name, F, p, sigma, it, kind):
     # in binary64 land on +-1 ulp in binary32, a tie the two precisions break differently)
     if kind == "awgn":
         ref64 = run_oracle(oracle.dec_minsum, oc, llr32.astype(np.float64), s, it)
-        same = (ref64[3] == out["status"]) & (ref64[1] == out["iters"])
-        assert same.mean() > 0.9
+        # verdict and iteration count on every frame; the decoded word where the reference converged (a frame
+        # that fails in both precisions wanders: its bits after max_iter iterations are no point of comparison)
+        same = (ref64[3] == out["status"]) & (ref64[1] == out["iters"]) & \
+               ((ref64[3] != 0) | (ref64[0] == out["bits"]).all(axis=1))
+        print(f"ms32 vs the double reference, {name}: {same.sum()}/{len(same)} frames equal (verdict, iterations, converged words)")
+        assert same.all(), f"frames {np.where(~same)[0]} differ from the double reference"   # (measured: all, on every case)
 
 
 # (small_code, n = 12, has weight-2 checks that pass +-L straight through: with equal-magnitude
@@ -109,13 +113,14 @@ SPA_CASES = [("small_code.txt", 40, 0.03, 0.9, 8)] + \
 @pytest.mark.parametrize("kind", ["bsc", "awgn"])
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_spa_float(hip, oracle, name, F, p, sigma, it, kind, prec):
-    """libm differs between host and device in the last ulp, so the sum-product decoders are
-    compared on decoded bits with a margin filter: a frame counts when the oracle's final
-    posteriors hold no NaN (the reference's log tanh(0) = -inf hazard, test_code_B_float.c:149,168,
-    makes a frame's outcome depend on whether a sum cancels exactly) and all have |sum| > MARGIN.
-    On those frames verdict, iteration count and every decoded bit must be EQUAL -- 100 %, no
-    allowance -- and the filter may not drop more than half of the frames.  (Measured in round 2,
-    tools/spa_diag.py: the frames the filter drops agree as well, on every case.)"""
+    """The sum-product decoders against their oracle (test_code_B_float.c:134-199): on EVERY frame whose
+    oracle posteriors hold no NaN, verdict, iteration count and every decoded bit must be EQUAL -- no
+    allowance, and no margin filter on this check (round 2 measured the device's own exp / log routines
+    against glibc on these cases: all 1 958 frames agree, profiles/r02_spa_agreement.txt; the test now
+    demands what was measured).  Frames with the reference's NaN (its log tanh(0) = -inf hazard, :149,:168:
+    the outcome depends on whether a sum cancels exactly) are counted and printed, and at least 95 % of
+    them must agree as well.  The margin (frames whose oracle posteriors all keep |sum| > MARGIN) only
+    selects the frames on which posterior LLR values are compared, to the relative tolerance RTOL."""
     MARGIN = {"f64": 1e-6, "f32": 1e-2}[prec]
     RTOL = {"f64": 1e-6, "f32": 2e-2}[prec]
     oc = oracle.load(code_path(name))
@@ -133,11 +138,13 @@ def test_spa_float(hip, oracle, name, F, p, sigma, it, kind, prec):
     post = ref[4]
     nan = np.isnan(post).any(axis=1)
     safe = ~nan & (np.abs(np.where(np.isnan(post), 1.0, post)).min(axis=1) > MARGIN)
-    assert safe.sum() >= 0.5 * F, f"margin filter removed {F - safe.sum()} of {F} frames"
     agree = (out["status"] == ref[3]) & (out["iters"] == ref[1]) & (out["bits"] == ref[0]).all(axis=1)
-    print(f"spa {prec} {name} {kind}: {agree[safe].sum()}/{safe.sum()} safe frames equal, {agree.sum()}/{F} of all "
-          f"({nan.sum()} with the reference's NaN)")
-    assert agree[safe].all(), f"spa {prec} {name} {kind}: frames {np.where(safe & ~agree)[0]} differ"
+    print(f"spa {prec} {name} {kind}: {agree[~nan].sum()}/{(~nan).sum()} NaN-free frames equal, {agree[nan].sum()}/{nan.sum()} "
+          f"of the frames with the reference's NaN")
+    assert (~nan).sum() >= 0.6 * F, f"{nan.sum()} of {F} frames hit the reference's NaN: the case tests too little"
+    assert agree[~nan].all(), f"spa {prec} {name} {kind}: frames {np.where(~nan & ~agree)[0]} differ"
+    assert agree[nan].sum() >= 0.95 * nan.sum() - 1e-9, f"spa {prec} {name} {kind}: NaN frames {np.where(nan & ~agree)[0]} differ"
+    assert np.array_equal(out["synd"][~nan], ref[2][~nan])
     if prec == "f32":
         assert not np.isnan(out["llr"][~nan]).any(), "binary32 NaN on a frame where its twin has none"
     # posterior LLRs of frames that ran all iterations on both sides

@@ -24,7 +24,22 @@ class _Hip:
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
         self.held = []
+
+    def free_bytes(self):
+        """Free device memory as the runtime sees it (after everything queued has finished)."""
+        fr, tot = self.C.c_size_t(), self.C.c_size_t()
+        assert self.rt.hipDeviceSynchronize() == 0
+        assert self.rt.hipMemGetInfo(self.C.byref(fr), self.C.byref(tot)) == 0
+        return fr.value
+
+    def stream(self):
+        st = self.C.c_void_p()
+        assert self.rt.hipStreamCreate(self.C.byref(st)) == 0
+        return st
 
     def up(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -66,11 +81,14 @@ def _run(hip, dec, code, inp, synd, it, noalloc, want_llr=False):
     dt = {np.dtype(np.int16): hip.DT.I16, np.dtype(np.float32): hip.DT.F32, np.dtype(np.float64): hip.DT.F64,
           np.dtype(np.int32): hip.DT.I32}[inp.dtype]
     try:
+        before = g.free_bytes()
         dec.decode_device(F, d_in, dt, it, d_sy, bits, iters, sout, status, post, None, noalloc=noalloc)
+        after = g.free_bytes()
         out = dict(bits=g.down(bits, (F, code.n), np.uint8), synd=g.down(sout, (F, code.m), np.uint8),
                    iters=g.down(iters, (F,), np.int32), status=g.down(status, (F,), np.int32))
         if want_llr:
             out["llr"] = g.down(post, (F, code.n), np.float32)
+        out["_allocated"] = before - after      # device bytes the call itself took from the runtime
     finally:
         g.free()
     return out
@@ -83,7 +101,8 @@ CASES = [
     ("204.33.484.txt", "MINSUM_Q88", {"cn_variant": 5}, 700, 129, 0.05),       # two-pass, int16 messages, 2 slabs then 1
     ("204.33.484.txt", "SPA_F32", {"want_llr": True}, 300, 50, 0.05),          # two-pass binary32 + posterior LLRs
     ("204.33.484.txt", "SPA_TABLE_Q14", {"early_exit": True}, 260, 64, 0.04),  # two-pass int32, host early-exit polls
-    # staircase frame-resident kernel: its per-workgroup rows come out of the scratch (170 workgroups' worth fit)
+    # staircase frame-resident kernel: its per-workgroup rows (R * block * 10 B = 320 KiB for this code) come out of
+    # the scratch, so the grid is capped at the 102 workgroups whose rows fit 32 MiB
     ("dvb_H_0.5.txt", "MINSUM_Q88", {}, 300, 9, 0.05),
 ]
 
@@ -115,7 +134,12 @@ def test_noalloc_equals_the_allocating_entry_point_twice_in_a_row(hip, oracle, t
         if F == f1:
             assert (ref["status"] == 0).any(), "the first call should hold frames that converge"
         for k in ref:       # (the float sum-product keeps the reference's NaN hazards: NaN == NaN here)
-            assert np.array_equal(ref[k], got[k], equal_nan=(k == "llr")), (name, alg, F, k)
+            if k != "_allocated":
+                assert np.array_equal(ref[k], got[k], equal_nan=(k == "llr")), (name, alg, F, k)
+        # the point of the entry: the call takes no device memory from the runtime (the allocating entry may,
+        # on its first call; by the second call of either kind everything lazily allocated exists)
+        if F == f2:
+            assert got["_allocated"] == 0, f"the allocation-free call allocated {got['_allocated']} bytes"
     dec.close()
 
 
@@ -138,7 +162,8 @@ def test_noalloc_refuses_what_does_not_fit_and_stays_usable(hip, oracle):
     ref = _run(hip, dec, code, raw[:1000], sy[:1000], 10, False)
     got = _run(hip, dec, code, raw[:1000], sy[:1000], 10, True)
     for k in ref:
-        assert np.array_equal(ref[k], got[k]), k
+        if k != "_allocated":
+            assert np.array_equal(ref[k], got[k]), k
     # non-binary decoders are not served
     g = hip.Code.from_alist(code_path("q4.sp.9000.6000.4500.1"))
     gd = hip.Decoder(g, hip.ALG.GF2P_WHT, max_frames=2)
@@ -150,3 +175,79 @@ def test_noalloc_refuses_what_does_not_fit_and_stays_usable(hip, oracle):
     mem.free()
     dec.close()
     gd.close()
+
+
+def test_noalloc_refuses_overlapping_calls(hip, oracle):
+    """Every call on a GPU works in that GPU's one static array, so two calls must not overlap: a call that
+    arrives while another is on the host (two host threads), or while the previous call's kernels are still
+    running on ANOTHER stream, is refused with LDPC_ERR_ARG instead of racing; the same stream, or any
+    stream once that work is done, is served."""
+    import threading
+    import time
+    name = "1057.244.3.txt"
+    oc = oracle.load(code_path(name))
+    code = hip.Code.from_alist(code_path(name))
+    F = 2048
+    x, s, llr = make_frames(oracle, oc, F, 0.09, 3, "bsc")            # far above threshold: nothing converges
+    raw = to_q88(llr)[1]
+    g = _Hip()
+    d_in = g.up(raw)
+    bitsA, statA = g.filled((F, code.n), np.uint8, 0), g.filled((F,), np.int32, 0)
+    bitsB, statB = g.filled((F, code.n), np.uint8, 0), g.filled((F,), np.int32, 0)
+    # (a) two host threads: A's call polls the host every iteration (early exit on, two-pass engine) and
+    # stays in the library for 254 iterations; B knocks meanwhile
+    decA = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=F, early_exit=True, cn_variant=5)
+    decB = hip.Decoder(code, hip.ALG.MINSUM_Q88, max_frames=64, early_exit=False)
+    started, finished = threading.Event(), threading.Event()
+    errs = []
+
+    def a_side():
+        try:
+            started.set()
+            decA.decode_device(F, d_in, hip.DT.I16, 254, None, bitsA, None, None, statA, None, None, noalloc=True)
+        except Exception as e:          # noqa: BLE001 -- reported below
+            errs.append(e)
+        finally:
+            finished.set()
+    th = threading.Thread(target=a_side)
+    th.start()
+    started.wait()
+    time.sleep(0.002)
+    refused = served = 0
+    while not finished.is_set():
+        try:
+            decB.decode_device(8, d_in, hip.DT.I16, 2, None, bitsB, None, None, statB, None, None, noalloc=True)
+            served += 1
+        except hip.LdpcError as e:
+            assert e.code == -4 and "another call" in str(e)
+            refused += 1
+    th.join()
+    assert not errs, errs
+    assert refused > 0, f"no call of thread B met thread A's ({served} served)"
+    assert g.rt.hipDeviceSynchronize() == 0
+    refA = g.down(statA, (F,), np.int32)
+    assert (refA == 1).all()
+    # (b) two streams: an asynchronous call (early exit off: the call returns while its kernel runs) on one
+    # stream, then a call on another stream
+    peg = hip.Code.from_alist(code_path("peg_16000_3_0.9.txt"))
+    Fp = 4096
+    rng = np.random.default_rng(1)
+    big = np.where(rng.random((Fp, peg.n)) < 0.02, -996, 996).astype(np.int16)
+    d_big = g.up(big)
+    bitsP, statP = g.filled((Fp, peg.n), np.uint8, 0), g.filled((Fp,), np.int32, 0)
+    decP = hip.Decoder(peg, hip.ALG.MINSUM_Q88, max_frames=Fp, early_exit=False)
+    s1, s2 = g.stream(), g.stream()
+    decP.decode_device(Fp, d_big, hip.DT.I16, 200, None, bitsP, None, None, statP, None, s1.value, noalloc=True)
+    decP.decode_device(64, d_big, hip.DT.I16, 200, None, bitsP, None, None, statP, None, s1.value, noalloc=True)   # same stream: ordered
+    with pytest.raises(hip.LdpcError) as e:
+        decP.decode_device(64, d_big, hip.DT.I16, 10, None, bitsP, None, None, statP, None, s2.value, noalloc=True)
+    assert e.value.code == -4 and "another stream" in str(e.value)
+    assert g.rt.hipDeviceSynchronize() == 0
+    decP.decode_device(64, d_big, hip.DT.I16, 10, None, bitsP, None, None, statP, None, s2.value, noalloc=True)  # idle now: served
+    assert g.rt.hipDeviceSynchronize() == 0
+    assert (g.down(statP, (64,), np.int32) == 1).all()
+    g.rt.hipStreamDestroy(s1)
+    g.rt.hipStreamDestroy(s2)
+    g.free()
+    for d in (decA, decB, decP):
+        d.close()

@@ -1,1 +1,2 @@
-for st in 1 0; do for it in 0 1 2 10; do LDPC_HIP_FUSED_STAGE=$st timeout -k 10 200 python3 bench.py --no-cpu --no-secondary --no-pmc --iters $it 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage', $st, 'iters', $it, d['ms_per_step'])"; done; done
+# ms per step of the bench workload against the number of iterations executed (fixed cost = the 0-iteration line)
+for it in 0 1 2 10; do timeout -k 10 200 python3 bench.py --no-cpu --no-secondary --no-pmc --no-configs --no-verify --iters $it 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('iters', $it, d['ms_per_step'])"; done
