@@ -708,6 +708,9 @@ def main():
                     roofline["sq"] = {c: round(counters[c] / wc, 4) for c in
                                       ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c in counters}
                     roofline["sq"]["note"] = "shares of SQ_WAVE_CYCLES, from the profiled (lower-clocked) pass"
+                    for c in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"):
+                        if c in counters:
+                            roofline["sq"][c + "_per_launch"] = int(counters[c])
             else:
                 roofline = {"bound": "hbm", "achieved": round(ach_hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach_hbm / HBM_PEAK_GBS, 4),

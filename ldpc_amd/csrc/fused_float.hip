@@ -62,6 +62,7 @@ struct FfArgs {
   // register-cached kernel only
   const uint16_t *vtabT;   // [VPT*CM][block]  (check << 5) | shift of its sign bit, per (thread, variable, edge)
   const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
+  const uint32_t *colP;    // binary64 register-cached kernel: packed slot addresses, [rounds][R2 / PK][block][PK]
   // QG kernels (frames whose q0 does not fit beside the sums): the channel LLRs in placed order,
   // one row of var_words values per workgroup, in global memory (L2 / Infinity Cache resident)
   void *q0g;
@@ -645,6 +646,298 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-cached binary64 variant (round 3): dec() of test_code_min_sum_B.c:137-208 in the
+// reference's own arithmetic with every index in VGPRs, as fused_ms_reg_kernel has them for
+// binary32.  What differs is where things live, because binary64 sums of a 16 000-variable frame
+// are 128 KB of the 160 KB:
+//   LDS     sum[words] binary64 (placed by the schedule compiler); per check {min1, min2} as one
+//           16-byte pair, its sign word, and one byte for the slot of min1 (the packed records of
+//           the QG kernels above)
+//   VGPRs   q0 of the thread's VPT variables (there is no LDS left for it, and a per-workgroup row in
+//           global memory -- the QG kernels' way, and this kernel's first build -- streams 128 KB per
+//           frame-iteration from the Infinity Cache: 4.5 TB/s of fabric traffic, 64 % of the wave cycles
+//           parked, 18 Gbit/s), (check, sign shift) of every edge of those variables, the compressed
+//           state of the thread's checks
+//   global  the slot addresses of the thread's checks (a.colP: two 16-bit entries per word, each the
+//           sum's index * 4 -- the byte address is twice that): a read-only table of 100 KB that every
+//           workgroup shares, so it lives in L2, read a chunk ahead of its use with 16-byte loads
+// Every floating-point operation is the reference's, on the same operands in the same order.
+#ifndef FF64_PKMAX
+#define FF64_PKMAX 4
+#endif
+// packed slot-address words per load (2 slots each) of the binary64 register-cached kernel
+constexpr int ff64_pk(int r2) { return (r2 % 4 == 0 && FF64_PKMAX >= 4) ? 4 : (r2 % 2 == 0 && FF64_PKMAX >= 2) ? 2 : 1; }
+typedef __attribute__((address_space(3))) double lds_double;
+typedef double ff_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) ff_d2 lds_d2;
+typedef __attribute__((address_space(3))) unsigned lds_uint;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template <int HI>
+__device__ __forceinline__ lds_double *ff_dslot_ptr(unsigned packed) {
+  unsigned r;   // entry = index * 4; the dynamic LDS starts at address 0 (checked on the host)
+  if (HI) asm volatile("v_lshrrev_b32 %0, 15, %1\n\tv_and_b32 %0, 0x7fff8, %0" : "=&v"(r) : "v"(packed));
+  else asm volatile("v_and_b32 %0, 0xffff, %1\n\tv_add_u32 %0, %0, %0" : "=&v"(r) : "v"(packed));
+  return (lds_double *)(unsigned long)r;
+}
+template <int HI>
+__device__ __forceinline__ unsigned ff_check_of(unsigned packed) {
+  unsigned r;   // volatile: not hoisted out of the iteration loop (a register per edge)
+  if (HI) asm volatile("v_bfe_u32 %0, %1, 21, 11" : "=v"(r) : "v"(packed));
+  else asm volatile("v_bfe_u32 %0, %1, 5, 11" : "=v"(r) : "v"(packed));
+  return r;
+}
+
+template <int CPT, int R2, int VPT, int CM, int LB, int MINW>
+__global__ __launch_bounds__(LB, MINW) void fused_ms_reg64_kernel(FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double ffsum64[];   // [words] sums, then the records
+  constexpr int RM = 2 * R2;
+  static_assert(RM <= 32, "one sign word per check");
+  constexpr int NE = VPT * CM, NE2 = (NE + 1) / 2;
+  constexpr int B = LB;
+  const int tid = threadIdx.x;
+  ff_d2 *mag = (ff_d2 *)(ffsum64 + a.words);                  // [m + 1] {min1, min2}     (words is even: 16-byte aligned)
+  unsigned *sgL = (unsigned *)(mag + a.m + 1);                // [m + 1] sign words
+  unsigned char *argL = (unsigned char *)(sgL + a.m + 1);     // [m + 1] slot of min1 (as a shift: 32 - RM + slot)
+  int *frame_slot = (int *)(((size_t)(argL + a.m + 1) + 3) & ~(size_t)3);
+  const unsigned magbase = (unsigned)a.words * 8u;
+  const unsigned sgbase = magbase + (unsigned)(a.m + 1) * 16u;
+  const unsigned argbase = sgbase + (unsigned)(a.m + 1) * 4u;
+  // slot addresses: PK packed words (2 PK slots) per load, [round][chunk][thread][PK] (host: colP)
+  constexpr int PK = ff64_pk(R2);
+  constexpr int NCH = R2 / PK;                 // chunks per check
+  constexpr int CH = 2 * PK;                   // slots per chunk
+  typedef unsigned ff_pk __attribute__((ext_vector_type(PK)));
+  // (uniform base + one 32-bit lane offset: the chunk's position is scalar arithmetic, not an address register pair per chunk)
+  const ff_pk *colP = (const ff_pk *)a.colP;
+
+  bool has[CPT];
+  unsigned allm[CPT];
+  unsigned vidx[NE2];
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    has[r] = r < a.rounds && r * B + tid < a.m;
+    allm[r] = r < a.rounds ? a.maskT[(size_t)r * B + tid] : 0u;
+  }
+#pragma unroll
+  for (int e2 = 0; e2 < NE2; e2++) {
+    const unsigned lo = a.vtabT[(size_t)(2 * e2) * B + tid];
+    const unsigned hi = 2 * e2 + 1 < NE ? a.vtabT[(size_t)(2 * e2 + 1) * B + tid] : ((unsigned)a.m << 5);
+    vidx[e2] = lo | (hi << 16);
+    asm volatile("" : "+v"(vidx[e2]));
+  }
+  const bool wave_full = __ballot(has[CPT - 1]) != 0;
+  const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const fq_u4 *pos8 = (const fq_u4 *)a.pos;
+
+  for (int i = a.dummy_base + tid; i < a.words; i += B) ffsum64[i] = 1e30;     // pad slots: sign 0, never a minimum
+  for (int i = tid; i < a.var_words; i += B) ffsum64[i] = 0.0;                 // (words that hold no variable)
+  if (tid == 0) {
+    ff_d2 none; none.x = 0.0; none.y = 0.0;                     // "no edge": message -0.0
+    mag[a.m] = none; sgL[a.m] = 0xffffffffu; argL[a.m] = 0xff;
+  }
+  int q_next = 0, q_lim = 0;
+  auto take_frame = [&]() {
+    if (q_next == q_lim) { q_next = atomicAdd(a.counter, a.chunk); q_lim = q_next + a.chunk; }
+    return q_next++;
+  };
+  if (tid == 0) *frame_slot = take_frame();
+  __syncthreads();
+  for (;;) {
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+    int next_frame = 0;
+    if (tid == 0) next_frame = take_frame();
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 0 && (a.n & 1) == 0 && ((size_t)a.llr & 15) == 0) {
+        const ff_d2 *p2 = (const ff_d2 *)((const double *)a.llr + base);
+        const unsigned *pos2 = (const unsigned *)a.pos;
+        for (int i = tid; i < (a.n >> 1); i += B) {
+          const ff_d2 v = __builtin_nontemporal_load(p2 + i);
+          const unsigned w = pos2[i];
+          ffsum64[w & 0xffffu] = v.x + 0.0;
+          ffsum64[w >> 16] = v.y + 0.0;
+        }
+      } else if (a.dt == 0) {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) ffsum64[a.pos[i]] = p[i] + 0.0;
+      } else {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) ffsum64[a.pos[i]] = (double)p[i] + 0.0;
+      }
+    }
+    double om1[CPT], om2[CPT];
+    unsigned oarg[CPT], osg[CPT];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      om1[r] = om2[r] = 0.0;
+      oarg[r] = 0u; osg[r] = 0u;
+      sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
+      par[r] = 0;
+    }
+    if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
+    __syncthreads();
+    // q0 of this thread's variables (the sums start as q0 + 0.0; the zero's sign never reaches a result)
+    double q0v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int w = tid + B * i;
+      q0v[i] = (i < VPT - 2 || w < a.var_words) ? ffsum64[w] : 0.0;
+    }
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      int bad = 0;
+      // one check at a time (the binary32 kernel interleaves a thread's checks; with 64-bit values
+      // that working set does not fit beside the index registers -- 73 spilled registers)
+      auto check_pass = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          double m1 = (double)FF_CAP, m2 = (double)FF_CAP;
+          unsigned arg = 0u, pp = 0u;
+          unsigned sg = osg[r] << (32 - RM);      // old signs leave at the top while the new ones enter at the bottom
+          unsigned long long ob[5];               // the slot of the previous minimum, one lane mask per bit (scalar registers)
+#pragma unroll
+          for (int b = 0; b < 5; b++) ob[b] = __ballot((oarg[r] >> b) & 1u);
+          ff_pk pk = colP[(unsigned)((r * NCH) * B) + (unsigned)tid];
+#pragma unroll
+          for (int kc = 0; kc < RM; kc += CH) {
+            // this chunk's slot addresses are here; the next chunk's (the next check's first) are requested now
+            unsigned ix[PK];
+#pragma unroll
+            for (int j = 0; j < PK; j++) ix[j] = pk[j];
+            if (kc + CH < RM || r + 1 < NA) pk = colP[(unsigned)((r * NCH + kc / CH + 1) * B) + (unsigned)tid];
+            double S[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) S[j] = (j & 1) ? *ff_dslot_ptr<1>(ix[j >> 1]) : *ff_dslot_ptr<0>(ix[j >> 1]);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+              const int k = kc + j;
+              if (k >= RM) continue;
+              if ((j & 1) == 0) pp = __builtin_amdgcn_bitop3_b32(pp, ff_hi(S[j]), ff_hi(S[j + 1]), 0x96);
+              unsigned long long in_k = (k & 1) ? ob[0] : ~ob[0];
+#pragma unroll
+              for (int b = 1; b < 5; b++) in_k &= ((k >> b) & 1) ? ob[b] : ~ob[b];
+              const double mo = ff_pick(om1[r], om2[r], in_k);                  // min2 in the slot of min1
+              const double co = __hiloint2double((int)FQ_ANDOR(sg, 0x80000000u, (unsigned)__double2hiint(mo)), __double2loint(mo));
+              const double q = S[j] - co;                                       // :150
+              sg = __builtin_amdgcn_alignbit(sg, ff_hi(q), 31);
+              const bool lt = ff_abs_lt(q, m1);
+              m2 = ff_min2(m2, ff_max_abs(m1, q));
+              arg = lt ? (unsigned)k : arg;
+              m1 = ff_min_abs(m1, q);
+            }
+            asm volatile("" : "+v"(pp), "+v"(m1), "+v"(m2), "+v"(arg), "+v"(sg));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const unsigned p = pp >> 31;
+          par[r] = (int)p;
+          bad |= has[r] ? ((int)p ^ sbit[r]) : 0;
+          const unsigned tot = (unsigned)sbit[r] ^ (unsigned)__popc(sg);
+          osg[r] = (tot & 1u) ? (sg ^ allm[r]) : sg;
+          om1[r] = m1; om2[r] = m2; oarg[r] = arg;
+          asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]), "+v"(osg[r]));
+          if (has[r]) {
+            const int j = r * B + tid;
+            ff_d2 mm; mm.x = om1[r]; mm.y = om2[r];
+            mag[j] = mm; sgL[j] = osg[r]; argL[j] = (unsigned char)(oarg[r] + (unsigned)(32 - RM));
+          }
+        }
+      };
+      auto parity_only = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          unsigned pp = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const ff_pk pk = colP[(unsigned)((r * NCH + c) * B) + (unsigned)tid];
+#pragma unroll
+            for (int j = 0; j < PK; j++) {
+              const unsigned ix = pk[j];
+              const double s0 = *ff_dslot_ptr<0>(ix);
+              const double s1 = *ff_dslot_ptr<1>(ix);
+              pp = __builtin_amdgcn_bitop3_b32(pp, ff_hi(s0), ff_hi(s1), 0x96);
+            }
+          }
+          par[r] = (int)(pp >> 31);
+          bad |= has[r] ? (par[r] ^ sbit[r]) : 0;
+        }
+      };
+      if (t == a.max_iter + 1) {
+        if (wave_full) parity_only(std::integral_constant<int, CPT>{});
+        else parity_only(std::integral_constant<int, CPT - 1>{});
+      } else if (wave_full) check_pass(std::integral_constant<int, CPT>{});
+      else check_pass(std::integral_constant<int, CPT - 1>{});
+      const int any_bad = fq_block_or(bad, frame_slot + 1, t);
+      if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      // ---- variable pass
+#pragma unroll
+      for (int i = 0; i < VPT; i++) {
+        ff_d2 mg[CM];
+        unsigned sw[CM], ar[CM];
+#pragma unroll
+        for (int kk = 0; kk < CM; kk++) {
+          const int e = i * CM + kk;
+          const unsigned cj = (e & 1) ? ff_check_of<1>(vidx[e >> 1]) : ff_check_of<0>(vidx[e >> 1]);
+          mg[kk] = *(lds_d2 *)(unsigned long)(magbase + cj * 16u);
+          sw[kk] = *(lds_uint *)(unsigned long)(sgbase + cj * 4u);
+          ar[kk] = *(lds_u8 *)(unsigned long)(argbase + cj);
+        }
+        const int w = tid + B * i;
+        double sum = q0v[i];
+#pragma unroll
+        for (int kk = 0; kk < CM; kk++) {
+          const int e = i * CM + kk;
+          const unsigned sh = (e & 1) ? ff_rec_shift<1>(vidx[e >> 1]) : ff_rec_shift<0>(vidx[e >> 1]);
+          const double m = (ar[kk] == sh) ? mg[kk].y : mg[kk].x;
+          sum = sum + __hiloint2double((int)FQ_ANDOR(sw[kk] << sh, 0x80000000u, (unsigned)__double2hiint(m)), __double2loint(m));
+        }
+        if (i < VPT - 2 || w < a.var_words) ffsum64[w] = sum + 0.0;
+        __builtin_amdgcn_sched_barrier(0);   // bounds the records in flight (live registers)
+      }
+      __syncthreads();
+    }
+
+    const unsigned *us = (const unsigned *)ffsum64;      // (sign of sum: bit 31 of its high word)
+    if (vec_out) {
+      fq_u2 *o8 = (fq_u2 *)(a.bits + (size_t)frame * a.n);
+      for (int i = tid; i < (a.n >> 3); i += B) {
+        const fq_u4 w = pos8[i];
+        fq_u2 b;
+        b.x = (us[2 * (w.x & 0xffffu) + 1] >> 31) | ((us[2 * (w.x >> 16) + 1] >> 31) << 8) | ((us[2 * (w.y & 0xffffu) + 1] >> 31) << 16) | ((us[2 * (w.y >> 16) + 1] >> 31) << 24);
+        b.y = (us[2 * (w.z & 0xffffu) + 1] >> 31) | ((us[2 * (w.z >> 16) + 1] >> 31) << 8) | ((us[2 * (w.w & 0xffffu) + 1] >> 31) << 16) | ((us[2 * (w.w >> 16) + 1] >> 31) << 24);
+        __builtin_nontemporal_store(b, o8 + i);
+      }
+    } else if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = ffsum64[a.pos[i]] < 0.0;
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = (float)ffsum64[a.pos[i]];
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (has[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    if (tid == 0) *frame_slot = next_frame;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // the shapes the register-cached kernel is built for: {checks per thread, slot pairs, variables
 // per thread, edges per variable}
 #define FF_REG_SHAPES(X) \
@@ -653,6 +946,13 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg_kernel(FfArgs a) {
   X(1, 7, 6, 3, 256, 4)    /* 1057.244.3: four */ \
   X(1, 3, 2, 3, 128, 4)    /* 204.33.484: eight */ \
   X(1, 5, 2, 7, 1024, 4)   /* Frolov_1024_0.5 (the Verilog trace's code): irregular, column weights to 7 */
+
+// the same for the binary64 register-cached kernel
+#define FF_REG64_SHAPES(X) \
+  X(2, 16, 16, 3, 1024, 4) /* peg_16000_3_0.9 */ \
+  X(2, 9, 10, 3, 512, 4)   /* 4095.737.3 */ \
+  X(1, 7, 6, 3, 256, 4)    /* 1057.244.3 */ \
+  X(1, 3, 2, 3, 128, 4)    /* 204.33.484 */
 
 namespace {
 
@@ -679,13 +979,20 @@ FfKern ff_reg_lookup(int cpt, int r2, int vpt, int cm, int block) {
   return nullptr;
 }
 
+FfKern ff_reg64_lookup(int cpt, int r2, int vpt, int cm, int block) {
+#define FF_X(C, R, V, M, LB, MW) if (cpt == C && r2 == R && vpt == V && cm == M && block == LB) return fused_ms_reg64_kernel<C, R, V, M, LB, MW>;
+  FF_REG64_SHAPES(FF_X)
+#undef FF_X
+  return nullptr;
+}
+
 template <typename T>
 struct FusedFloatEngine : Engine {
   ldpc_opts opts{};
   int n = 0, m = 0, rmax = 0, cmax = 0, RM = 0, NW = 1;
   int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
   size_t lds = 0;
-  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter, d_vtabT, d_maskT;
+  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter, d_vtabT, d_maskT, d_colP;
   LdsSchedule sched;
   FfKern kern = nullptr;
   bool use_reg = false;
@@ -731,11 +1038,12 @@ struct FusedFloatEngine : Engine {
       for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
     int rc;
 
-    // First choice: the register-cached binary32 kernel, if one is built for this shape.  Try
+    // First choice: the register-cached kernel (binary32 or binary64), if one is built for this shape.  Try
     // the workgroup shapes in order of SIMD balance (wavefronts go to the 4 SIMDs in turn; the
     // busiest sets the pace; a wavefront of the last, partial round runs the shorter stream).
     use_reg = false;
-    if (env_reg && sizeof(T) == 4 && NW == 1 && m <= 2047 && cmax >= 1) {
+    constexpr bool F64 = sizeof(T) == 8;
+    if (env_reg && NW == 1 && m <= 2047 && cmax >= 1) {
       std::vector<std::pair<double, int>> cand;
       for (int W = 1; W <= 16; W++) {
         if (env_w && W != env_w) continue;
@@ -754,15 +1062,21 @@ struct FusedFloatEngine : Engine {
         if (ldpc_build_lds_schedule(c, B, RM, FF_NDUMMY, optimise != 0, sc)) continue;
         int vpt = (sc.var_words + B - 1) / B;
         if ((cmax & 1) && (vpt & 1)) vpt++;
-        FfKern k = ff_reg_lookup(sc.rounds, RM / 2, vpt, cmax, B);
+        FfKern k = F64 ? ff_reg64_lookup(sc.rounds, RM / 2, vpt, cmax, B) : ff_reg_lookup(sc.rounds, RM / 2, vpt, cmax, B);
         if (getenv("LDPC_HIP_DEBUG"))
           fprintf(stderr, "fused float: shape {%d checks/thread, %d slot pairs, %d variables/thread, %d edges/variable, %d threads}: %s\n",
                   sc.rounds, RM / 2, vpt, cmax, B, k ? "built" : "no register-cached kernel");
         if (!k) continue;
         hipFuncAttributes fa;
         HIPCHK(hipFuncGetAttributes(&fa, (const void *)k));
-        if ((size_t)sc.words * 4 + fa.sharedSizeBytes > 65535) continue;   // 16-bit absolute slot addresses
-        const size_t need_lds = (size_t)sc.words * 4 + (size_t)(m + 1) * 16 + (size_t)sc.var_words * 4 + 16;
+        if (F64) {
+          // binary64: sums, {min1, min2} pairs, sign words, one byte per check; q0 in global memory.  The
+          // kernel addresses its dynamic LDS from 0 and packs index * 4 in 16 bits.
+          if (sc.words & 1) sc.words++;                                   // (16-byte alignment of the pairs)
+          if (fa.sharedSizeBytes != 0 || (size_t)sc.words * 4 > 65535) continue;
+        } else if ((size_t)sc.words * 4 + fa.sharedSizeBytes > 65535) continue;   // 16-bit absolute slot addresses
+        const size_t need_lds = F64 ? (size_t)sc.words * 8 + (size_t)(m + 1) * 21 + 3 + 16
+                                    : (size_t)sc.words * 4 + (size_t)(m + 1) * 16 + (size_t)sc.var_words * 4 + 16;
         if (need_lds + fa.sharedSizeBytes > 160 * 1024) continue;
         if (optimise) ldpc_place_variable_pass(c, sc, &vconf_before, &vconf_after);
         // edges of the variables each thread rebuilds: (check << 5) | shift of the sign bit
@@ -792,8 +1106,23 @@ struct FusedFloatEngine : Engine {
         if (lost) continue;
         sched = sc;
         kern = k; use_reg = true;
+        qg = false;
         block = B; rounds = sc.rounds;
         lds = need_lds;
+        if (F64) {
+          // the binary64 kernel's slot addresses: index * 4 in 16 bits, two per word, PK words per load,
+          // [round][chunk][thread][PK]
+          const int R2 = RM / 2, PK = ff64_pk(R2);
+          std::vector<uint32_t> cp((size_t)sc.rounds * R2 * B, 0u);
+          for (int r = 0; r < sc.rounds; r++)
+            for (int k2 = 0; k2 < R2; k2++)
+              for (int t = 0; t < B; t++) {
+                const uint32_t lo = sc.colT[((size_t)r * RM + 2 * k2) * B + t], hi = sc.colT[((size_t)r * RM + 2 * k2 + 1) * B + t];
+                cp[(((size_t)r * (R2 / PK) + k2 / PK) * B + t) * PK + k2 % PK] = (lo * 4u) | ((hi * 4u) << 16);
+              }
+          if ((rc = d_colP.ensure(cp.size() * 4))) return rc;
+          HIPCHK(hipMemcpy(d_colP.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+        }
         if ((rc = d_vtabT.ensure(vt.size() * 2))) return rc;
         if ((rc = d_maskT.ensure(sc.maskT.size() * 4))) return rc;
         HIPCHK(hipMemcpy(d_vtabT.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
@@ -918,6 +1247,7 @@ struct FusedFloatEngine : Engine {
     a.q0g = ws_q0g ? ws_q0g : d_q0g.p;
     a.vtabT = d_vtabT.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
+    a.colP = d_colP.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
     a.chunk = (int)std::max<long>(1, std::min<long>(std::min<long>(4096 / n, nframes / (grid * 16)), 16));
