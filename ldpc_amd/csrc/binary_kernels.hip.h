@@ -278,23 +278,23 @@ __device__ __forceinline__ float spa_atanh2exp(float x) {
 // Worst relative error against exact arithmetic 4.4e-13 on [-9, -5e-13] (the literal glibc forms: 2.2e-13 / 8.3e-13:
 // all of it the rounding of 1 -+ e); NaN in -> NaN out, -inf -> 0.
 #ifndef LDPC_SPA_F64_LIBM
+// (polynomial coefficients from constant memory: they arrive in scalar registers and enter v_fma_f64 as its
+// one scalar operand; as literals each costs a 64-bit move into a vector register in front of a v_fmac -- a
+// third of the old kernel's instructions were such moves)
+__device__ __constant__ double SPA_EXPC[13] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0,
+                                               1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0,
+                                               1.0 / 24.0, 1.0 / 6.0, -6.93147180369123816490e-01, -1.90821492927058770002e-10};
+__device__ __constant__ double SPA_LOGC[12] = {1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0,
+                                               1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0, 1.90821492927058770002e-10, 6.93147180369123816490e-01};
 __device__ __forceinline__ double spa_exp64(double x, double &p, int &k) {
   x = x < -750.0 ? -750.0 : x;
   const double kf = __builtin_rint(x * 1.4426950408889634);
   k = (int)kf;
-  double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
-  double q = 1.0 / 6227020800.0;
-  q = __builtin_fma(q, r, 1.0 / 479001600.0);
-  q = __builtin_fma(q, r, 1.0 / 39916800.0);
-  q = __builtin_fma(q, r, 1.0 / 3628800.0);
-  q = __builtin_fma(q, r, 1.0 / 362880.0);
-  q = __builtin_fma(q, r, 1.0 / 40320.0);
-  q = __builtin_fma(q, r, 1.0 / 5040.0);
-  q = __builtin_fma(q, r, 1.0 / 720.0);
-  q = __builtin_fma(q, r, 1.0 / 120.0);
-  q = __builtin_fma(q, r, 1.0 / 24.0);
-  q = __builtin_fma(q, r, 1.0 / 6.0);
+  double r = __builtin_fma(kf, SPA_EXPC[11], x);
+  r = __builtin_fma(kf, SPA_EXPC[12], r);
+  double q = SPA_EXPC[0];
+#pragma unroll
+  for (int i = 1; i < 11; i++) q = __builtin_fma(q, r, SPA_EXPC[i]);
   q = __builtin_fma(q, r, 0.5);
   p = __builtin_fma(q * r, r, r);
   return __builtin_ldexp(1.0 + p, k);
@@ -316,19 +316,12 @@ __device__ __forceinline__ double spa_logq64(double num, double den) {   // num,
   k2 += ad - an;
   const double s = spa_div64(mn - md, mn + md);               // (mn + md in (0.7, 3))
   const double z = s * s;
-  double t = 1.0 / 21.0;
-  t = __builtin_fma(t, z, 1.0 / 19.0);
-  t = __builtin_fma(t, z, 1.0 / 17.0);
-  t = __builtin_fma(t, z, 1.0 / 15.0);
-  t = __builtin_fma(t, z, 1.0 / 13.0);
-  t = __builtin_fma(t, z, 1.0 / 11.0);
-  t = __builtin_fma(t, z, 1.0 / 9.0);
-  t = __builtin_fma(t, z, 1.0 / 7.0);
-  t = __builtin_fma(t, z, 1.0 / 5.0);
-  t = __builtin_fma(t, z, 1.0 / 3.0);
+  double t = SPA_LOGC[0];
+#pragma unroll
+  for (int i = 1; i < 10; i++) t = __builtin_fma(t, z, SPA_LOGC[i]);
   const double s2 = s + s, k2f = (double)k2;
-  const double res = __builtin_fma(s2 * z, t, __builtin_fma(k2f, 1.90821492927058770002e-10, s2));
-  return __builtin_fma(k2f, 6.93147180369123816490e-01, res);
+  const double res = __builtin_fma(s2 * z, t, __builtin_fma(k2f, SPA_LOGC[10], s2));
+  return __builtin_fma(k2f, SPA_LOGC[11], res);
 }
 __device__ __forceinline__ double spa_logtanh2(double a) {            // a >= 0 (or NaN)
   double p; int k;
@@ -347,7 +340,29 @@ __device__ __forceinline__ double spa_atanh2exp(double x) {           // x <= 0 
   res = den == 0.0 ? __builtin_huge_val() : res;
   return x != x ? x : res;
 }
+// Round 3: the register-resident binary64 check node works in the tanh domain -- the product of the
+// others' tanh(a/2) in place of exp(sum of the others' log tanh), test_code_B_float.c:159-178 with the
+// logarithm and the exponential that cancel left out: per edge one e^-a, one division, one logarithm of
+// a quotient instead of two, two and two.  What is behaviour stays: t = tanh(a/2) is rounded to binary64
+// exactly as before (so a message's weight is exactly 1, its log exactly 0, from a > 38.1), the product of
+// the others is their exact leave-one-out product (prefix x suffix, no division by the own factor), so
+// e = 1 -- atanh2(1) = +inf, the reference's NaN hazard one pass later -- exactly when every other edge is
+// saturated, and 1 + e, 1 - e are rounded one by one as atanh2() rounds them; t = 0 (a zero message, whose
+// log tanh is -inf in the reference) sends 0 to the other edges and NaN to its own, as -inf - (-inf) does.
+#define LDPC_SPA_F64_PRODUCT 1
+__device__ __forceinline__ double spa_tanh_half64(double a) {            // tanh(a / 2), a >= 0 (or NaN)
+  double p; int k;
+  const double u = spa_exp64(-a, p, k);
+  const double qd = spa_div64(k == 0 ? -p : u + u, k == 0 ? 2.0 + p : 1.0 + u);
+  return k == 0 ? qd : 1.0 - qd;
+}
+__device__ __forceinline__ double spa_atanh2_64(double e) {              // log((1 + e) / (1 - e)), 0 <= e <= 1 (or NaN)
+  const double den = 1.0 - e;
+  double res = spa_logq64(1.0 + e, den);
+  return den == 0.0 ? __builtin_huge_val() : res;      // (a NaN runs through spa_logq64 as a NaN; 1 - NaN != 0)
+}
 #else   // the literal formulas on the device library (A/B builds)
+#define LDPC_SPA_F64_PRODUCT 0
 __device__ __forceinline__ double spa_logtanh2(double a) { return log(tanh(a * 0.5)); }
 __device__ __forceinline__ double spa_atanh2exp(double x) { double e = exp(x); return log((1.0 + e) / (1.0 - e)); }
 #endif
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(256) void cn_single_read_kernel(
 // 4.65 -> 5.78 Gbit/s, Frolov 2.51 -> 3.17, binary64 +4-6 %.  The 8-row ones are left alone: DVB-S2 unchanged,
 // (204,102) 4-5 % slower with the attribute)
 #ifndef LDPC_CN_REG_WAVES
-#define LDPC_CN_REG_WAVES __attribute__((amdgpu_waves_per_eu((ALG == ALG_SPA && RB >= 16) ? 4 : 1)))
+#define LDPC_CN_REG_WAVES __attribute__((amdgpu_waves_per_eu((ALG == ALG_SPA && (RB >= 16 || sizeof(T) == 8)) ? 4 : 1)))
 #endif
 // Register-resident variant for row weights <= RB: the whole check lives in
 // VGPRs between the load and the store (no LDS, no second read).
@@ -659,6 +674,42 @@ __global__ __launch_bounds__(256) LDPC_CN_REG_WAVES void cn_reg_kernel(
       // differences as the two-sweep kernels, half the transcendentals, one read of the rows
       static_assert(RB * V <= 64, "sign mask");
       unsigned long long negm = 0;
+      if constexpr (std::is_same<T, double>::value && LDPC_SPA_F64_PRODUCT) {
+        // tanh domain (see spa_tanh_half64): one frame of the lane at a time, the rows' registers take
+        // tanh(|v2c| / 2) and then the outgoing message in place
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          double pre[RB];        // product of the rows before k
+          double run = 1.0;
+#pragma unroll
+          for (int k = 0; k < RB; k++)
+            if (k < dc) {
+              const double xv = x[k][v];
+              const bool neg = xv < 0;
+              const double t = spa_tanh_half64(neg ? -xv : xv);
+              pre[k] = run;
+              run = run * t;
+              x[k][v] = t;
+              negm |= (unsigned long long)(neg ? 1u : 0u) << (k * V + v);
+              sg ^= (neg ? 1u : 0u) << v;
+            }
+          double suf = 1.0;      // product of the rows after k
+#pragma unroll
+          for (int k = RB - 1; k >= 0; k--)
+            if (k < dc) {
+              const double t = x[k][v];
+              double tout = spa_atanh2_64(pre[k] * suf);
+              tout = t == 0.0 ? __builtin_nan("") : tout;            // the reference's -inf - (-inf)
+              suf = suf * t;
+              const unsigned flip = ((unsigned)(negm >> (k * V + v)) ^ (sg >> v)) & 1u;       // sgnprod != the row's own sign
+              x[k][v] = __hiloint2double(__double2hiint(tout) ^ (int)(flip << 31), __double2loint(tout));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RB; k++)
+          if (k < dc) rows[(size_t)k * 64] = x[k];
+        continue;
+      }
       double lp[V];              // (binary64 sum: see cn_compute)
 #pragma unroll
       for (int v = 0; v < V; v++) lp[v] = 0;

@@ -382,9 +382,14 @@ def test_fused_float_minsum_on_random_shapes(hip, oracle, tmp_path, n, m, dv, it
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_spa_register_kernel_equals_two_sweep_kernels(hip, oracle, tmp_path, name, F, p, it, prec):
     """The register-resident sum-product check kernel (default for row weights <= 16, e.g. the
-    DVB-S2 code) evaluates log tanh once per row and keeps it; the two-sweep kernels evaluate
-    it twice.  Same device libm, same values, same order of sums: every output must be
-    identical, posterior LLRs included, whichever kernel ran."""
+    DVB-S2 code) against the two-sweep kernels.  binary32: it evaluates log tanh once per row and
+    keeps it where the others evaluate it twice -- same functions, same values, same order of sums:
+    every output must be identical, posterior LLRs included, whichever kernel ran.  binary64 (round 3):
+    the register kernel works in the tanh domain (the product of the others' tanh(a/2) in place of
+    exp(sum of their log tanh), binary_kernels.hip.h spa_tanh_half64), the two-sweep kernels keep the
+    sum of logarithms: the same mathematics with different roundings, so verdicts, iteration counts,
+    syndromes and the words of the converged frames must be equal and the posteriors agree to 1e-9
+    relative (median; NaN where the other has NaN)."""
     path = code_path(name)
     if name.startswith("dvb"):     # (the reference-style loader of the oracle needs the padded dialect)
         path = str(tmp_path / "padded.alist")
@@ -399,9 +404,22 @@ def test_spa_register_kernel_equals_two_sweep_kernels(hip, oracle, tmp_path, nam
     for variant in (0, 3, 2, 1):
         dec = hip.Decoder(code, alg, max_frames=256, want_llr=True, cn_variant=variant)
         outs.append(dec.decode(inp, s.astype(np.uint8), it, want=want))
-    for o in outs[1:]:
+    for i, o in enumerate(outs[1:]):
+        same_math = prec == "f32" or i == 0            # (variant 3 IS the default register kernel)
         for k in want:
-            assert np.array_equal(o[k], outs[0][k], equal_nan=True) if k == "llr" else np.array_equal(o[k], outs[0][k]), k
+            if k == "llr":
+                if same_math:
+                    assert np.array_equal(o[k], outs[0][k], equal_nan=True), k
+                else:
+                    a, b = o[k].astype(np.float64), outs[0][k].astype(np.float64)
+                    fin = np.isfinite(a) & np.isfinite(b)
+                    assert fin.mean() > 0.9
+                    assert np.median(np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1.0)) < 1e-9
+            elif k == "bits" and not same_math:
+                conv = outs[0]["status"] == 0
+                assert np.array_equal(o[k][conv], outs[0][k][conv]), k
+            else:
+                assert np.array_equal(o[k], outs[0][k]), k
 
 
 @pytest.mark.parametrize("name,F,sigma,it", [("dvb_H_0.5.txt", 5, 0.84, 50), ("Frolov_1024_0.5.txt", 60, 0.62, 30),
