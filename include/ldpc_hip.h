@@ -327,6 +327,32 @@ int  ldpc_mc_generate(ldpc_mc *mc, const ldpc_mc_opts *o, int nframes, uint8_t *
 /* The last pass of ldpc_mc_run copied to the host (its first nframes frames). */
 int  ldpc_mc_last_pass(ldpc_mc *mc, int nframes, uint8_t *x, uint8_t *bits, int32_t *status, int32_t *iters);
 
+/* ------------------------------------------- the GF(q) trial loop on the device
+ * The trial loop of GFq_LDPC() (GFq_LDPC.c:620-650; WD_farm/GFq_LDPC.c:600-630) with every step on the
+ * GPU, as ldpc_mc_* is for the binary harnesses: x[i] = rand() % Q (:626), s = enc(x) (:632, :299-310),
+ * channel() (:213-231: the read y walks the column of the sent symbol in the confusion matrix with a
+ * percent-granular uniform draw) and assign_llr() (:199-211: logfna[.][i] = log P(sent | y), floor -100),
+ * dec() (GFQ_DIRECT or GF2P_WHT decoder `d`), classification (:641-649).  Eight counters cross PCIe.
+ * Draws are counter-based, keyed by (seed, global frame index): frames do not depend on the pass size or
+ * on the number of ranks (shard a run through first_frame). */
+typedef struct ldpc_gfmc ldpc_gfmc;
+int  ldpc_gfmc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_gfmc **out);
+void ldpc_gfmc_free(ldpc_gfmc *mc);
+/* p_rec_given_sent[q * num_reads][q], P(read r | sent a), columns already normalised as GFq_LDPC() does
+ * (:548-558): make_p_sent_given_rec_T() (:177-197) and the log / -100 floor of assign_llr(). */
+int  ldpc_gfmc_set_channel(ldpc_gfmc *mc, const double *p_rec_given_sent, int num_reads);
+/* counters[8] = {frames, not converged (errors[0]), converged to a word != x (errors[1]), symbol errors,
+ * iterations executed, frames with any symbol error, symbol errors of converged frames, 0}. */
+int  ldpc_gfmc_run(ldpc_gfmc *mc, int max_iter, int64_t nframes, uint64_t seed, uint64_t first_frame,
+                   uint64_t *counters);
+/* Generation only, for inspection (at most one pass): x[nframes][n] one symbol per byte, the reads
+ * y[nframes][n], the uniform draws sel[nframes][n] behind them, logfna[nframes][n][q], synd[nframes][m];
+ * any pointer may be NULL.  GFq_LDPC_experiment() restates the same frames on the host. */
+int  ldpc_gfmc_generate(ldpc_gfmc *mc, uint64_t seed, uint64_t first_frame, int nframes, uint8_t *x,
+                        int32_t *y, float *sel, double *logfna, uint8_t *synd);
+/* The last pass of ldpc_gfmc_run copied to the host (its first nframes frames). */
+int  ldpc_gfmc_last_pass(ldpc_gfmc *mc, int nframes, uint8_t *x, uint8_t *xhat, int32_t *status, int32_t *iters);
+
 /* ------------------------------------------- reference-shaped entry points
  * Same names, argument order and meaning as the reference's C harness
  * functions; `errors` is the caller's double[2] = {not converged, converged to
@@ -385,7 +411,9 @@ int GFq_LDPC(const char *code_filename, int iteration, int num_trials, int num_s
  * (:213-231), logfna[n][q] = log P(a sent | y_i) with the -100 floor (assign_llr, :199-211,
  * tables from make_p_sent_given_rec_T, :177-197) and the percent-granular uniform draws
  * rand_select[n] behind y (the reference takes them from rand(), seeded from the clock, so
- * the stream itself cannot be matched; the channel law can, draw by draw).  p_rec_given_sent
+ * the stream itself cannot be matched; the channel law can, draw by draw).  Frame f of this call
+ * is frame f of ldpc_gfmc_generate / ldpc_gfmc_run for the same seed (counter-based draws): the
+ * host restatement of what the device front-end decodes.  p_rec_given_sent
  * is column-normalised in place.  s, y, rand_select may be NULL.  Host only; needs no GPU. */
 int GFq_LDPC_experiment(const char *code_filename, int num_reads, double *p_rec_given_sent,
                         uint64_t seed, int nframes, int32_t *x, int32_t *s, int32_t *y,

@@ -6,8 +6,8 @@ package is the thin ctypes caller the reference's Python prototype
 (LDPC_decode.py) would use: ``ldpc_amd.ldpc_decode.run(H, LLR, max_iter)``.
 There is no CPU fallback: decoding without the HIP library / a GPU raises.
 """
-from .lib import (ALG, CH, DT, SRC, Code, Decoder, LdpcError, MonteCarlo, lib_path, load_library)  # noqa: F401
+from .lib import (ALG, CH, DT, SRC, Code, Decoder, GfMonteCarlo, LdpcError, MonteCarlo, lib_path, load_library)  # noqa: F401
 from . import alist, ldpc_decode  # noqa: F401
 
-__all__ = ["ALG", "CH", "DT", "SRC", "Code", "Decoder", "LdpcError", "MonteCarlo", "alist", "ldpc_decode",
+__all__ = ["ALG", "CH", "DT", "SRC", "Code", "Decoder", "GfMonteCarlo", "LdpcError", "MonteCarlo", "alist", "ldpc_decode",
            "lib_path", "load_library"]

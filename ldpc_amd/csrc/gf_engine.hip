@@ -936,10 +936,37 @@ __global__ void gf_state_out_kernel(FrameState s, int nframes, int32_t *iters_ou
   if (status_out) status_out[f] = s.status[f];
 }
 
+// ---- second stage of a two-stage decode (GfEngine::decode; the binary two-pass engine's BinaryEngine::decode has
+// the same shape): the frames still open when the first stage stops are listed, their inputs gathered into a
+// dense batch, decoded again from scratch and their results written back over the first stage's
+__global__ void gf_list_open_kernel(int nframes, const uint8_t *frozen, int *count, int *idx) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < nframes && !frozen[f]) idx[atomicAdd(count, 1)] = f;
+}
+// rows of `row` 4-byte words (or bytes): dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter)
+template <typename U, bool SCATTER>
+__global__ void gf_move_rows_kernel(const U *__restrict__ src, U *__restrict__ dst, const int *__restrict__ idx, size_t row) {
+  const size_t i = blockIdx.x, f = (size_t)idx[blockIdx.x];
+  const U *sp = src + (SCATTER ? i : f) * row;
+  U *dp = dst + (SCATTER ? f : i) * row;
+  for (size_t k = threadIdx.x; k < row; k += blockDim.x) dp[k] = sp[k];
+}
+template <bool SCATTER>
+static void gf_move_rows(const void *src, void *dst, const int *idx, int count, size_t row_bytes, hipStream_t st) {
+  if (count <= 0 || !src || !dst) return;
+  if (row_bytes % 4 == 0 && ((size_t)src | (size_t)dst) % 4 == 0)
+    hipLaunchKernelGGL((gf_move_rows_kernel<uint32_t, SCATTER>), dim3((unsigned)count), dim3(256), 0, st, (const uint32_t *)src,
+                       (uint32_t *)dst, idx, row_bytes / 4);
+  else
+    hipLaunchKernelGGL((gf_move_rows_kernel<uint8_t, SCATTER>), dim3((unsigned)count), dim3(256), 0, st, (const uint8_t *)src,
+                       (uint8_t *)dst, idx, row_bytes);
+}
+
 // ------------------------------------------------------------------ engine
 
 template <typename T, bool WHT>
 struct GfEngine : Engine {
+  DevBuf s2_idx, s2_llr, s2_synd, s2_bits, s2_iters, s2_sout, s2_status;
   ldpc_opts opts{};
   int n = 0, m = 0, E = 0, Q = 0, rmax = 0;
   int G = 1, Fpad_max = 0;
@@ -1121,9 +1148,62 @@ struct GfEngine : Engine {
     return (unsigned)b;
   }
 
+  // Two stages when frames may leave early and the batch is large (round 3; the reference's dec() returns as
+  // soon as ITS frame is done, GFq_LDPC.c:459-463, GFq_LDPC_NTT.c:527-540): the [edge][frame][Q] rows keep every
+  // frame of a batch in the passes until the last one stops, so a batch in which most frames converge in a few
+  // iterations and a handful need max_iter costs max_iter for all.  The first stage stops once at most 1/16 of
+  // the frames are open (and >= 8 iterations remain); those frames are decoded again from their priors as a dense
+  // batch.  dec() is deterministic: every frame's word, iteration count, syndrome and verdict are the one-stage
+  // decode's.  LDPC_HIP_TWO_STAGE=0 turns it off.
   int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
              int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
              hipStream_t st) override {
+    const char *ts_env = getenv("LDPC_HIP_TWO_STAGE");
+    const bool two = (!ts_env || atoi(ts_env) != 0) && opts.early_exit != 0 && nframes >= 16 * G && nframes >= 256 &&
+                     max_iter >= 16 && (dt == LDPC_DT_F64 || dt == LDPC_DT_F32 || dt == LDPC_DT_I32);
+    if (!two) return decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, 0, nullptr);
+    bool stopped = false;
+    int rc = decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, nframes / 16, &stopped);
+    if (rc || !stopped) return rc;
+    const int stage1 = last_iterations;
+    if ((rc = s2_idx.ensure(sizeof(int) * ((size_t)nframes / 16 + 64)))) return rc;
+    int *d_count = s2_idx.as<int>(), *d_idx = s2_idx.as<int>() + 32;
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(int), st));
+    hipLaunchKernelGGL(gf_list_open_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, nframes, fs.frozen, d_count, d_idx);
+    LAUNCHCHK("gf_list_open_kernel");
+    int count = 0;
+    HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (count <= 0) return LDPC_OK;
+    if (count > nframes / 16) { ldpc_set_error("two-stage decode: more open frames than the first stage reported"); return LDPC_ERR_HIP; }
+    const size_t in_row = (size_t)n * Q * (dt == LDPC_DT_F64 ? 8 : 4);
+    if ((rc = s2_llr.ensure(in_row * count))) return rc;
+    if (sy_in && (rc = s2_synd.ensure((size_t)m * count))) return rc;
+    if (bits && (rc = s2_bits.ensure((size_t)n * count))) return rc;
+    if (iters_out && (rc = s2_iters.ensure(sizeof(int32_t) * count))) return rc;
+    if (sout_out && (rc = s2_sout.ensure((size_t)m * count))) return rc;
+    if (status && (rc = s2_status.ensure(sizeof(int32_t) * count))) return rc;
+    gf_move_rows<false>(llr, s2_llr.p, d_idx, count, in_row, st);
+    if (sy_in) gf_move_rows<false>(sy_in, s2_synd.p, d_idx, count, (size_t)m, st);
+    LAUNCHCHK("gf_move_rows_kernel (gather)");
+    rc = decode_once(count, s2_llr.p, dt, sy_in ? s2_synd.as<uint8_t>() : nullptr, max_iter, bits ? s2_bits.as<uint8_t>() : nullptr,
+                     iters_out ? s2_iters.as<int32_t>() : nullptr, sout_out ? s2_sout.as<uint8_t>() : nullptr,
+                     status ? s2_status.as<int32_t>() : nullptr, nullptr, st, 0, nullptr);
+    if (rc) return rc;
+    if (bits) gf_move_rows<true>(s2_bits.p, bits, d_idx, count, (size_t)n, st);
+    if (iters_out) gf_move_rows<true>(s2_iters.p, iters_out, d_idx, count, sizeof(int32_t), st);
+    if (sout_out) gf_move_rows<true>(s2_sout.p, sout_out, d_idx, count, (size_t)m, st);
+    if (status) gf_move_rows<true>(s2_status.p, status, d_idx, count, sizeof(int32_t), st);
+    LAUNCHCHK("gf_move_rows_kernel (scatter)");
+    last_iterations = std::max(last_iterations, stage1);
+    return LDPC_OK;
+  }
+
+  // stop_open > 0: leave the iteration loop once at most stop_open frames are still open, provided at least 8
+  // iterations remain (*stopped tells); those frames come out as "not converged" and are decoded again
+  int decode_once(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+                  int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+                  hipStream_t st, int stop_open, bool *stopped) {
     if (nframes <= 0) return LDPC_OK;
     prof_cur_frames = nframes;
     if (llr_out) {
@@ -1275,6 +1355,7 @@ struct GfEngine : Engine {
         if (t >= 1) {
           HIPCHK(hipEventSynchronize(ev[(t - 1) % 4]));
           if (h_remaining[t - 1] == 0) break;
+          if (stop_open > 0 && h_remaining[t - 1] <= stop_open && max_iter - (t + 1) >= 8) { *stopped = true; break; }
         }
       }
     }

@@ -34,24 +34,18 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "engine.h"
+#include "mc_rng.h"
 
 namespace {
 
-constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
-
-__host__ __device__ inline uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-// stream: 0 source bits, 1 channel
-__host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t frame, uint64_t stream) {
-  return mix64(seed ^ mix64(frame * 4 + stream + GOLDEN));
-}
-__host__ __device__ inline uint64_t draw(uint64_t key, uint64_t i) { return mix64(key + (i + 1) * GOLDEN); }
+using ldpc_rng::GOLDEN;
+using ldpc_rng::mix64;
+using ldpc_rng::stream_key;
+using ldpc_rng::draw;
 
 struct McArgs {
   int n, m, nw;               // nw = ceil(n / 32) bitmap words per frame
@@ -492,6 +486,246 @@ extern "C" int ldpc_mc_last_pass(ldpc_mc *mc, int nframes, uint8_t *x, uint8_t *
   const size_t n = (size_t)mc->code->n;
   if (x) HIPCHK(hipMemcpy(x, mc->d_x.p, nframes * n, hipMemcpyDeviceToHost));
   if (bits) HIPCHK(hipMemcpy(bits, mc->d_bits.p, nframes * n, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(hipMemcpy(status, mc->d_status.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(hipMemcpy(iters, mc->d_iters.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The trial loop of GFq_LDPC() (GFq_LDPC.c:540-655; WD_farm/GFq_LDPC.c:477-633) on the device.
+// Per trial the reference draws x[i] = rand() % Q (:626), s = enc(x) (:632), sends x through
+// channel() (:213-248: the read y walks the column of the sent symbol in the confusion matrix with a
+// percent-granular uniform draw, logfna[.][i] = log p(sent | y) with the -100 floor, :199-211), runs
+// dec() and classifies.  Here: gfmc_gen_kernel (one thread per symbol), gfmc_synd_kernel (one thread per
+// check), the decoder on those device buffers, gfmc_classify_kernel -- eight counters cross PCIe.
+namespace {
+
+struct GfmcArgs {
+  int n, m, Q, R, nframes;
+  uint64_t seed, first_frame;
+  const double *conf;      // [R][Q] P(read r | sent a), column-normalised
+  const double *logT;      // [R][Q] log P(sent a | read r), floor -100
+  const int32_t *row_ptr, *col_idx, *hval;
+  const uint8_t *mul;      // [Q][Q] GF(q) multiplication
+  int pow2;                // field addition: XOR (2^p) or mod q (prime)
+  uint8_t *x;              // [nframes][n]
+  int32_t *y;              // [nframes][n] or null
+  float *sel;              // [nframes][n] or null
+  double *logfna;          // [nframes][n][Q]
+  uint8_t *synd;           // [nframes][m]
+};
+
+__global__ __launch_bounds__(256) void gfmc_gen_kernel(GfmcArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)a.nframes * a.n) return;
+  const int f = (int)(t / a.n), i = (int)(t % a.n);
+  const uint64_t fr = a.first_frame + (uint64_t)f;
+  const int xi = (int)ldpc_rng::below(draw(stream_key(a.seed, fr, 0), (uint64_t)i), (uint32_t)a.Q);
+  const float sel = ldpc_rng::percent(draw(stream_key(a.seed, fr, 1), (uint64_t)i));
+  // channel(), :213-231.  No fused multiply-add: the walk must land in the bin the reference's doubles land in.
+  double temp = 0;
+  int rec = 0;
+  if (!sel)
+    while (rec < a.R && !a.conf[(rec++) * a.Q + xi]) {}
+  while (temp < (double)sel && rec != a.R) temp = __dadd_rn(temp, __dmul_rn(100.0, a.conf[(rec++) * a.Q + xi]));
+  const int yi = rec > 0 ? rec - 1 : 0;
+  a.x[t] = (uint8_t)xi;
+  if (a.y) a.y[t] = yi;
+  if (a.sel) a.sel[t] = sel;
+  double *lf = a.logfna + t * a.Q;
+  const double *row = a.logT + (size_t)yi * a.Q;
+  for (int q = 0; q < a.Q; q++) lf[q] = row[q];
+}
+
+// enc(), GFq_LDPC.c:299-310
+__global__ __launch_bounds__(256) void gfmc_synd_kernel(GfmcArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)a.nframes * a.m) return;
+  const int f = (int)(t / a.m), j = (int)(t % a.m);
+  const uint8_t *x = a.x + (size_t)f * a.n;
+  int acc = 0;
+  for (int e = a.row_ptr[j]; e < a.row_ptr[j + 1]; e++) {
+    const int prod = a.mul[x[a.col_idx[e]] * a.Q + a.hval[e]];
+    acc = a.pow2 ? (acc ^ prod) : (acc + prod) % a.Q;
+  }
+  a.synd[t] = (uint8_t)acc;
+}
+
+// as mc_classify_kernel, on symbols: 0 frames, 1 not converged, 2 converged to a word != x, 3 symbol errors,
+// 4 iterations, 5 frames with any symbol error, 6 symbol errors of converged frames
+__global__ __launch_bounds__(256) void gfmc_classify_kernel(int n, int nframes, const uint8_t *x, const uint8_t *xhat,
+                                                            const int32_t *status, const int32_t *iters,
+                                                            unsigned long long *counters) {
+  __shared__ unsigned long long acc[8];
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned long long c[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int f = blockIdx.x * nw + wave; f < nframes; f += gridDim.x * nw) {
+    const uint8_t *xr = x + (size_t)f * n, *br = xhat + (size_t)f * n;
+    int diff = 0;
+    for (int i = lane; i < n; i += 64) diff += xr[i] != br[i];
+    for (int o = 32; o > 0; o >>= 1) diff += __shfl_xor(diff, o);
+    const int st = status[f];
+    c[0] += 1ull;
+    if (st) c[1] += 1ull;
+    else if (diff) c[2] += 1ull;
+    if (diff) {
+      c[3] += (unsigned long long)diff;
+      c[5] += 1ull;
+      if (!st) c[6] += (unsigned long long)diff;
+    }
+    c[4] += (unsigned long long)iters[f];
+  }
+  if (lane == 0)
+    for (int k = 0; k < 7; k++)
+      if (c[k]) atomicAdd(&acc[k], c[k]);
+  __syncthreads();
+  if (threadIdx.x < 7 && acc[threadIdx.x]) atomicAdd(&counters[threadIdx.x], acc[threadIdx.x]);
+}
+
+}  // namespace
+
+struct ldpc_gfmc {
+  const ldpc_code *code = nullptr;
+  ldpc_decoder *dec = nullptr;
+  int device = 0, max_frames = 0, R = 0;
+  DevBuf d_row_ptr, d_col_idx, d_hval, d_mul, d_conf, d_logT;
+  DevBuf d_x, d_y, d_sel, d_logfna, d_synd, d_xhat, d_iters, d_status, d_counters;
+};
+
+extern "C" int ldpc_gfmc_create(const ldpc_code *c, ldpc_decoder *d, int device, ldpc_gfmc **out) {
+  if (!c || !d || !out) return LDPC_ERR_ARG;
+  if (c->q < 3 || c->q > 256) {
+    ldpc_set_error("ldpc_gfmc: the GF(q) Monte-Carlo front-end needs a non-binary code");
+    return LDPC_ERR_UNSUPPORTED;
+  }
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<ldpc_gfmc> mc(new ldpc_gfmc);
+  mc->code = c; mc->dec = d; mc->device = device;
+  mc->max_frames = ldpc_decoder_max_frames(d);
+  const size_t F = (size_t)mc->max_frames, n = (size_t)c->n, m = (size_t)c->m, Q = (size_t)c->q, E = (size_t)c->E();
+  int rc;
+  if ((rc = mc->d_row_ptr.ensure((m + 1) * 4)) || (rc = mc->d_col_idx.ensure(E * 4 + 4)) || (rc = mc->d_hval.ensure(E * 4 + 4)) ||
+      (rc = mc->d_mul.ensure(Q * Q)) || (rc = mc->d_x.ensure(F * n)) || (rc = mc->d_logfna.ensure(F * n * Q * 8)) ||
+      (rc = mc->d_synd.ensure(F * m + 4)) || (rc = mc->d_xhat.ensure(F * n)) || (rc = mc->d_iters.ensure(F * 4)) ||
+      (rc = mc->d_status.ensure(F * 4)) || (rc = mc->d_counters.ensure(64)))
+    return rc;
+  std::vector<uint8_t> mul(Q * Q);
+  for (size_t a = 0; a < Q; a++)
+    for (size_t b = 0; b < Q; b++) mul[a * Q + b] = (uint8_t)ldpc_gf_mul_host((int)Q, (int)a, (int)b);
+  HIPCHK(hipMemcpy(mc->d_row_ptr.p, c->row_ptr.data(), (m + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(mc->d_col_idx.p, c->col_idx.data(), E * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(mc->d_hval.p, c->hval.data(), E * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(mc->d_mul.p, mul.data(), Q * Q, hipMemcpyHostToDevice));
+  *out = mc.release();
+  return LDPC_OK;
+}
+
+extern "C" void ldpc_gfmc_free(ldpc_gfmc *mc) {
+  if (!mc) return;
+  (void)hipSetDevice(mc->device);
+  delete mc;
+}
+
+// make_p_sent_given_rec_T() + the -100 floor of assign_llr() (GFq_LDPC.c:177-211) from the column-normalised
+// confusion matrix p_rec_given_sent[q * num_reads][q]
+extern "C" int ldpc_gfmc_set_channel(ldpc_gfmc *mc, const double *p_rec_given_sent, int num_reads) {
+  if (!mc || !p_rec_given_sent || num_reads <= 0) return LDPC_ERR_ARG;
+  const int Q = mc->code->q, R = Q * num_reads;
+  std::vector<double> logT((size_t)R * Q);
+  const double P_x = 1 / (1.0 * Q);
+  for (int i = 0; i < R; i++) {
+    double P_y = 0;
+    for (int j = 0; j < Q; j++) P_y += p_rec_given_sent[i * Q + j] * P_x;
+    for (int j = 0; j < Q; j++) {
+      const double t = P_y ? P_x * p_rec_given_sent[i * Q + j] / P_y : 0.0;
+      logT[(size_t)i * Q + j] = t == 0 ? -100.0 : std::log(t);
+    }
+  }
+  HIPCHK(hipSetDevice(mc->device));
+  int rc;
+  if ((rc = mc->d_conf.ensure((size_t)R * Q * 8)) || (rc = mc->d_logT.ensure((size_t)R * Q * 8))) return rc;
+  HIPCHK(hipMemcpy(mc->d_conf.p, p_rec_given_sent, (size_t)R * Q * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(mc->d_logT.p, logT.data(), (size_t)R * Q * 8, hipMemcpyHostToDevice));
+  mc->R = R;
+  return LDPC_OK;
+}
+
+static int gfmc_generate_pass(ldpc_gfmc *mc, uint64_t seed, uint64_t first, int nf, bool inspect, hipStream_t st) {
+  const ldpc_code &c = *mc->code;
+  if (!mc->R) { ldpc_set_error("ldpc_gfmc: ldpc_gfmc_set_channel() first"); return LDPC_ERR_ARG; }
+  int rc;
+  if (inspect && ((rc = mc->d_y.ensure((size_t)mc->max_frames * c.n * 4)) || (rc = mc->d_sel.ensure((size_t)mc->max_frames * c.n * 4)))) return rc;
+  GfmcArgs a;
+  memset(&a, 0, sizeof a);
+  a.n = c.n; a.m = c.m; a.Q = c.q; a.R = mc->R; a.nframes = nf;
+  a.seed = seed; a.first_frame = first;
+  a.conf = mc->d_conf.as<double>(); a.logT = mc->d_logT.as<double>();
+  a.row_ptr = mc->d_row_ptr.as<int32_t>(); a.col_idx = mc->d_col_idx.as<int32_t>(); a.hval = mc->d_hval.as<int32_t>();
+  a.mul = mc->d_mul.as<uint8_t>();
+  a.pow2 = (c.q & (c.q - 1)) == 0;
+  a.x = mc->d_x.as<uint8_t>();
+  a.y = inspect ? mc->d_y.as<int32_t>() : nullptr;
+  a.sel = inspect ? mc->d_sel.as<float>() : nullptr;
+  a.logfna = mc->d_logfna.as<double>(); a.synd = mc->d_synd.as<uint8_t>();
+  const size_t ts = (size_t)nf * c.n, tc = (size_t)nf * c.m;
+  hipLaunchKernelGGL(gfmc_gen_kernel, dim3((unsigned)((ts + 255) / 256)), dim3(256), 0, st, a);
+  LAUNCHCHK("gfmc_gen_kernel");
+  hipLaunchKernelGGL(gfmc_synd_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, st, a);
+  LAUNCHCHK("gfmc_synd_kernel");
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_gfmc_generate(ldpc_gfmc *mc, uint64_t seed, uint64_t first_frame, int nframes, uint8_t *x, int32_t *y,
+                                  float *sel, double *logfna, uint8_t *synd) {
+  if (!mc || nframes < 0 || nframes > mc->max_frames) return LDPC_ERR_ARG;
+  if (nframes == 0) return LDPC_OK;
+  HIPCHK(hipSetDevice(mc->device));
+  int rc = gfmc_generate_pass(mc, seed, first_frame, nframes, true, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)mc->code->n, m = (size_t)mc->code->m, Q = (size_t)mc->code->q;
+  if (x) HIPCHK(hipMemcpy(x, mc->d_x.p, nframes * n, hipMemcpyDeviceToHost));
+  if (y) HIPCHK(hipMemcpy(y, mc->d_y.p, nframes * n * 4, hipMemcpyDeviceToHost));
+  if (sel) HIPCHK(hipMemcpy(sel, mc->d_sel.p, nframes * n * 4, hipMemcpyDeviceToHost));
+  if (logfna) HIPCHK(hipMemcpy(logfna, mc->d_logfna.p, nframes * n * Q * 8, hipMemcpyDeviceToHost));
+  if (synd) HIPCHK(hipMemcpy(synd, mc->d_synd.p, nframes * m, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
+
+extern "C" int ldpc_gfmc_run(ldpc_gfmc *mc, int max_iter, int64_t nframes, uint64_t seed, uint64_t first_frame,
+                             uint64_t *counters) {
+  if (!mc || nframes < 0 || max_iter < 0 || !counters) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(mc->device));
+  HIPCHK(hipMemsetAsync(mc->d_counters.p, 0, 64, nullptr));
+  int rc;
+  for (int64_t done = 0; done < nframes; done += mc->max_frames) {
+    const int nf = (int)std::min<int64_t>(mc->max_frames, nframes - done);
+    if ((rc = gfmc_generate_pass(mc, seed, first_frame + (uint64_t)done, nf, false, nullptr))) return rc;
+    rc = ldpc_decode_batch_device(mc->dec, nf, mc->d_logfna.p, LDPC_DT_F64, mc->d_synd.as<uint8_t>(), max_iter,
+                                  mc->d_xhat.as<uint8_t>(), mc->d_iters.as<int32_t>(), nullptr, mc->d_status.as<int32_t>(),
+                                  nullptr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gfmc_classify_kernel, dim3((unsigned)std::min(2048, (nf + 3) / 4)), dim3(256), 0, nullptr, mc->code->n, nf,
+                       mc->d_x.as<uint8_t>(), mc->d_xhat.as<uint8_t>(), mc->d_status.as<int32_t>(), mc->d_iters.as<int32_t>(),
+                       mc->d_counters.as<unsigned long long>());
+    LAUNCHCHK("gfmc_classify_kernel");
+  }
+  HIPCHK(hipMemcpy(counters, mc->d_counters.p, 64, hipMemcpyDeviceToHost));
+  return LDPC_OK;
+}
+
+// the decoded words / verdicts of the last pass of ldpc_gfmc_run (tests); host pointers, any may be null
+extern "C" int ldpc_gfmc_last_pass(ldpc_gfmc *mc, int nframes, uint8_t *x, uint8_t *xhat, int32_t *status, int32_t *iters) {
+  if (!mc || nframes < 0 || nframes > mc->max_frames) return LDPC_ERR_ARG;
+  HIPCHK(hipSetDevice(mc->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)mc->code->n;
+  if (x) HIPCHK(hipMemcpy(x, mc->d_x.p, nframes * n, hipMemcpyDeviceToHost));
+  if (xhat) HIPCHK(hipMemcpy(xhat, mc->d_xhat.p, nframes * n, hipMemcpyDeviceToHost));
   if (status) HIPCHK(hipMemcpy(status, mc->d_status.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
   if (iters) HIPCHK(hipMemcpy(iters, mc->d_iters.p, (size_t)nframes * 4, hipMemcpyDeviceToHost));
   return LDPC_OK;

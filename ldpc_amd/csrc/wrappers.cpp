@@ -18,6 +18,7 @@
 
 #include "../../include/ldpc_hip.h"
 #include "engine.h"
+#include "mc_rng.h"
 
 namespace {
 
@@ -417,11 +418,14 @@ struct GfqChannel {
     while (temp < sel && rec != R) temp += 100 * p[(rec++) * Q + xi];
     return rec > 0 ? rec - 1 : 0;
   }
-  // one frame: x[i] = rand() % Q (:626), y, logfna[i][*] (frame-major rows of Q); sel_out optional
-  void frame(Rng &r, int n, int32_t *xf, int32_t *yf, double *lf, float *sel_out) const {
-    for (int i = 0; i < n; i++) xf[i] = (int32_t)r.below((uint32_t)Q);
+  // one frame: x[i] = rand() % Q (:626), y, logfna[i][*] (frame-major rows of Q); sel_out optional.
+  // The draws are the device front-end's (mc_frontend.hip gfmc_gen_kernel): counter-based, keyed by
+  // (seed, global frame index), so this host restatement names the very frames ldpc_gfmc_run() decodes.
+  void frame(uint64_t seed, uint64_t index, int n, int32_t *xf, int32_t *yf, double *lf, float *sel_out) const {
+    const uint64_t k0 = ldpc_rng::stream_key(seed, index, 0), k1 = ldpc_rng::stream_key(seed, index, 1);
+    for (int i = 0; i < n; i++) xf[i] = (int32_t)ldpc_rng::below(ldpc_rng::draw(k0, (uint64_t)i), (uint32_t)Q);
     for (int i = 0; i < n; i++) {
-      const float sel = (float)(r.next() >> 40) * 100.0f / (float)((1u << 24) - 1);
+      const float sel = ldpc_rng::percent(ldpc_rng::draw(k1, (uint64_t)i));
       const int yi = draw(xf[i], sel);
       if (yf) yf[i] = yi;
       if (sel_out) sel_out[i] = sel;
@@ -443,39 +447,21 @@ static int gfq_trials(ldpc_code *code, ldpc_decoder *dec, int iteration, int num
     ldpc_set_error("GFq_LDPC: decode_mode 1 (page files) is not supported");
     return LDPC_ERR_UNSUPPORTED;
   }
-  int rc;
-  const int Q = ldpc_code_q(code), n = ldpc_code_n(code), m = ldpc_code_m(code);
+  // column normalisation in place (:548-558); the whole trial loop -- source symbols, enc(), channel(),
+  // dec(), classification -- then runs on the device (mc_frontend.hip, ldpc_gfmc_*): eight counters come back
   GfqChannel ch;
-  ch.prepare(Q, num_reads, p_rec_given_sent);
-
+  ch.prepare(ldpc_code_q(code), num_reads, p_rec_given_sent);
   Rng r = take_rng();
-  const int B = ldpc_decoder_max_frames(dec);
-  std::vector<int32_t> x((size_t)B * n), sx(m), status(B);
-  std::vector<uint8_t> s((size_t)B * m), xhat((size_t)B * n);
-  std::vector<double> logfna((size_t)B * n * Q);
-  for (int t0 = 0; t0 < num_trials; t0 += B) {
-    const int nf = num_trials - t0 < B ? num_trials - t0 : B;
-    for (int f = 0; f < nf; f++) {
-      int32_t *xf = &x[(size_t)f * n];
-      ch.frame(r, n, xf, nullptr, &logfna[(size_t)f * n * Q], nullptr);
-      ldpc_code_syndrome(code, xf, sx.data());
-      for (int j = 0; j < m; j++) s[(size_t)f * m + j] = (uint8_t)sx[j];
-    }
-    rc = ldpc_decode_batch(dec, nf, logfna.data(), LDPC_DT_F64, s.data(), iteration, xhat.data(), nullptr,
-                           nullptr, status.data(), nullptr);
-    if (rc) return rc;
-    for (int f = 0; f < nf; f++) {
-      if (status[f]) {
-        errors[0]++;
-      } else {
-        for (int i = 0; i < n; i++)
-          if ((int32_t)xhat[(size_t)f * n + i] != x[(size_t)f * n + i]) {
-            errors[1]++;
-            break;
-          }
-      }
-    }
-  }
+  ldpc_gfmc *mc = nullptr;
+  int rc = ldpc_gfmc_create(code, dec, cache_device(), &mc);
+  if (rc) return rc;
+  uint64_t counters[8] = {0};
+  rc = ldpc_gfmc_set_channel(mc, p_rec_given_sent, num_reads);
+  if (!rc) rc = ldpc_gfmc_run(mc, iteration, num_trials, r.next(), 0, counters);
+  ldpc_gfmc_free(mc);
+  if (rc) return rc;
+  errors[0] = (double)counters[1];
+  errors[1] = (double)counters[2];
   return LDPC_OK;
 }
 
@@ -495,9 +481,8 @@ extern "C" int GFq_LDPC_experiment(const char *code_filename, int num_reads, dou
   }
   GfqChannel ch;
   ch.prepare(Q, num_reads, p_rec_given_sent);
-  Rng r{seed};
   for (int f = 0; f < nframes; f++) {
-    ch.frame(r, n, x + (size_t)f * n, y ? y + (size_t)f * n : nullptr, logfna + (size_t)f * n * Q,
+    ch.frame(seed, (uint64_t)f, n, x + (size_t)f * n, y ? y + (size_t)f * n : nullptr, logfna + (size_t)f * n * Q,
              rand_select ? rand_select + (size_t)f * n : nullptr);
     if (s) ldpc_code_syndrome(code, x + (size_t)f * n, s + (size_t)f * m);
   }

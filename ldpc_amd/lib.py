@@ -101,6 +101,13 @@ def load_library():
     L.ldpc_mc_generate.argtypes = [vp, C.POINTER(_McOpts), ip, vp, vp, vp]
     L.ldpc_mc_last_pass.argtypes = [vp, ip, vp, vp, vp, vp]
     L.ldpc_mc_set_qlc_channel.argtypes = [vp, vp, ip]
+    L.ldpc_gfmc_create.argtypes = [vp, vp, ip, C.POINTER(vp)]
+    L.ldpc_gfmc_free.argtypes = [vp]
+    L.ldpc_gfmc_free.restype = None
+    L.ldpc_gfmc_set_channel.argtypes = [vp, vp, ip]
+    L.ldpc_gfmc_run.argtypes = [vp, ip, C.c_int64, C.c_uint64, C.c_uint64, vp]
+    L.ldpc_gfmc_generate.argtypes = [vp, C.c_uint64, C.c_uint64, ip, vp, vp, vp, vp, vp]
+    L.ldpc_gfmc_last_pass.argtypes = [vp, ip, vp, vp, vp, vp]
     L.ldpc_wht_tables_selfcheck.argtypes = [vp]
     L.ldpc_wht_tables_selfcheck.restype = C.c_int64
     L.ldpc_spa_tables_selfcheck.argtypes = [vp]
@@ -374,6 +381,61 @@ class MonteCarlo:
     def close(self):
         if self._h:
             load_library().ldpc_mc_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GfMonteCarlo:
+    """The trial loop of GFq_LDPC() on the device (include/ldpc_hip.h, ldpc_gfmc_*): source symbols, enc(),
+    the confusion-matrix channel, dec(), classification."""
+
+    COUNTERS = ("frames", "not_converged", "undetected", "symbol_errors", "iterations", "frames_in_error",
+                "symbol_errors_converged")
+
+    def __init__(self, code, decoder, device=0):
+        L = load_library()
+        self.code, self.decoder = code, decoder
+        h = C.c_void_p()
+        check(L.ldpc_gfmc_create(code._h, decoder._h, device, C.byref(h)))
+        self._h = h
+
+    def set_channel(self, p_rec_given_sent, num_reads):
+        """Confusion matrix [q * num_reads][q], columns normalised (GFq_LDPC.c:548-558)."""
+        p = np.ascontiguousarray(p_rec_given_sent, np.float64)
+        check(load_library().ldpc_gfmc_set_channel(self._h, _ptr(p), int(num_reads)))
+
+    def run(self, nframes, max_iter, seed=1, first_frame=0):
+        c = np.zeros(8, np.uint64)
+        check(load_library().ldpc_gfmc_run(self._h, int(max_iter), int(nframes), int(seed), int(first_frame), _ptr(c)))
+        return {k: int(c[i]) for i, k in enumerate(self.COUNTERS)}
+
+    def generate(self, nframes, seed=1, first_frame=0):
+        n, m, q = self.code.n, self.code.m, self.code.q
+        x = np.empty((nframes, n), np.uint8)
+        y = np.empty((nframes, n), np.int32)
+        sel = np.empty((nframes, n), np.float32)
+        lf = np.empty((nframes, n, q), np.float64)
+        s = np.empty((nframes, m), np.uint8)
+        check(load_library().ldpc_gfmc_generate(self._h, int(seed), int(first_frame), int(nframes), _ptr(x), _ptr(y),
+                                                _ptr(sel), _ptr(lf), _ptr(s)))
+        return x, y, sel, lf, s
+
+    def last_pass(self, nframes):
+        x = np.empty((nframes, self.code.n), np.uint8)
+        xhat = np.empty((nframes, self.code.n), np.uint8)
+        status = np.empty(nframes, np.int32)
+        iters = np.empty(nframes, np.int32)
+        check(load_library().ldpc_gfmc_last_pass(self._h, int(nframes), _ptr(x), _ptr(xhat), _ptr(status), _ptr(iters)))
+        return x, xhat, status, iters
+
+    def close(self):
+        if self._h:
+            load_library().ldpc_gfmc_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -277,3 +277,115 @@ def test_gfq_ldpc_graph_passing_boundary(hip):
     assert L.GFq_LDPC_graph(q, 3, 1, 0, 1, 0, conf.ctypes.data_as(dp), n, m, cmax, rmax, P(cw), P(rw), P(rlc), P(clr),
                             P(bad), P(H), e) < 0
     assert b"col_list" in L.ldpc_last_error()
+
+
+@pytest.mark.parametrize("fname,q,num_reads,alg", [("q4.sp.9000.6000.4500.1", 4, 1, "GFQ_DIRECT"),
+                                                    ("peg_4376_4_0.9_NB.txt", 13, 3, "GFQ_DIRECT"),
+                                                    ("peg_4376_4_0.9_NB.txt", 13, 1, "GFQ_DIRECT")])
+def test_gfq_trial_loop_on_the_device(hip, oracle, fname, q, num_reads, alg):
+    """The GF(q) Monte-Carlo front-end (ldpc_gfmc_*, mc_frontend.hip): the frames the device generates --
+    source symbols, reads, the uniform draws behind them, log-probabilities, syndromes -- equal the host
+    restatement GFq_LDPC_experiment() bit for bit (same counter-based draws), and that restatement is the
+    one tests/test_host_library.py holds against the oracle's channel(), draw by draw; the syndromes
+    also against the oracle's enc() here.  Then the counters of a multi-pass run equal what decoding the
+    same frames through ldpc_decode_batch and classifying on the host gives, and frames do not depend on
+    the pass size (first_frame)."""
+    import ctypes as C
+    L = hip.load_library()
+    rng = np.random.default_rng(q + num_reads)
+    R = q * num_reads
+    conf = rng.random((R, q)) * (0.0015 if q == 13 else 0.08)
+    for a in range(q):
+        conf[a * num_reads:(a + 1) * num_reads, a] += 1.0 / num_reads   # reads of the sent symbol dominate
+    conf[rng.random((R, q)) < 0.2] = 0.0
+    for a in range(q):
+        conf[a * num_reads, a] = max(conf[a * num_reads, a], 0.5)
+    norm = conf / conf.sum(axis=0, keepdims=True)
+    code = hip.Code.from_alist(code_path(fname))
+    n, m = code.n, code.m
+    dec = hip.Decoder(code, getattr(hip.ALG, alg), max_frames=24, early_exit=True)
+    mc = hip.GfMonteCarlo(code, dec)
+    mc.set_channel(norm, num_reads)
+    F, seed = 5, 424242
+    x, y, sel, lf, s = mc.generate(F, seed=seed, first_frame=3)
+    # the host restatement of the same frames (frames 0..7 of the seed; the device was asked for 3..7)
+    hx = np.zeros((8, n), np.int32); hs = np.zeros((8, m), np.int32); hy = np.zeros((8, n), np.int32)
+    hl = np.zeros((8, n, q), np.float64); hsel = np.zeros((8, n), np.float32)
+    mine = np.ascontiguousarray(conf, np.float64).copy()
+    rc = L.GFq_LDPC_experiment(code_path(fname).encode(), num_reads, mine.ctypes.data_as(C.POINTER(C.c_double)), seed, 8,
+                               hx.ctypes.data, hs.ctypes.data, hy.ctypes.data, hl.ctypes.data, hsel.ctypes.data)
+    assert rc == 0, L.ldpc_last_error()
+    assert np.allclose(mine, norm, rtol=0, atol=1e-15)
+    assert np.array_equal(x, hx[3:].astype(np.uint8)) and np.array_equal(y, hy[3:]) and np.array_equal(sel, hsel[3:])
+    assert np.array_equal(s, hs[3:].astype(np.uint8))
+    assert np.array_equal(lf, hl[3:]), "log-probabilities differ from the host restatement"
+    oc = oracle.load(code_path(fname))
+    for f in range(F):
+        assert np.array_equal(s[f], oracle.gf_enc(oc, q, x[f].astype(np.int32)))
+    assert (lf == -100).any() and len(np.unique(y)) > q // 2
+    # counters of a run in passes of 24 frames against the host-side classification of the same frames
+    total, it = 60, 12
+    c = mc.run(total, it, seed=seed)
+    hx = np.zeros((total, n), np.int32); hl = np.zeros((total, n, q), np.float64); hs = np.zeros((total, m), np.int32)
+    mine = np.ascontiguousarray(conf, np.float64).copy()
+    rc = L.GFq_LDPC_experiment(code_path(fname).encode(), num_reads, mine.ctypes.data_as(C.POINTER(C.c_double)), seed, total,
+                               hx.ctypes.data, hs.ctypes.data, None, hl.ctypes.data, None)
+    assert rc == 0
+    out = dec.decode(hl.reshape(total, n * q), hs.astype(np.uint8), it)
+    nconv = int((out["status"] != 0).sum())
+    print(f"gfmc {fname} reads={num_reads}: {nconv} of {total} frames fail, iterations {sorted(set(out['iters'].tolist()))}")
+    wrong = (out["bits"] != hx.astype(np.uint8)).any(axis=1)
+    assert c["frames"] == total and c["not_converged"] == nconv
+    assert c["undetected"] == int(((out["status"] == 0) & wrong).sum())
+    assert c["symbol_errors"] == int((out["bits"] != hx.astype(np.uint8)).sum())
+    assert c["iterations"] == int(out["iters"].sum())
+    # the last pass (frames 48..59) is still on the device
+    lx, lxh, lst, lit = mc.last_pass(12)
+    assert np.array_equal(lx, hx[48:].astype(np.uint8)) and np.array_equal(lxh, out["bits"][48:])
+    assert np.array_equal(lst, out["status"][48:]) and np.array_equal(lit, out["iters"][48:])
+    # sharding: the second half of the run as its own call
+    c2 = mc.run(total - 30, it, seed=seed, first_frame=30)
+    assert c2["not_converged"] == int((out["status"][30:] != 0).sum())
+    assert c2["symbol_errors"] == int((out["bits"][30:] != hx[30:].astype(np.uint8)).sum())
+    mc.close()
+    dec.close()
+
+
+@pytest.mark.parametrize("alg", ["GFQ_DIRECT", "GF2P_WHT"])
+def test_gf_two_stage_decode_equals_one_stage(hip, monkeypatch, alg):
+    """Early exit that frees work (GfEngine::decode, round 3): with most frames done after a few iterations and a
+    few that need many (or fail), the first stage stops at 1/16 open frames and the rest are decoded again as a
+    dense batch.  dec() is deterministic (GFq_LDPC.c:356-467, GFq_LDPC_NTT.c:437-544), so words, syndromes,
+    iteration counts and verdicts must equal the one-stage decode's, frame for frame."""
+    fname, q = "q4.sp.9000.6000.4500.1", 4
+    code = hip.Code.from_alist(code_path(fname))
+    n, m = code.n, code.m
+    F = 512
+    rng = np.random.default_rng(99)
+    x = rng.integers(0, q, size=(F, n)).astype(np.int32)
+    s = np.stack([code.syndrome(x[f]) for f in range(F)]).astype(np.uint8)
+    # symbol errors: a light channel for most frames, a heavy one for every 23rd (slow or failing frames)
+    perr = np.where(np.arange(F) % 23 == 0, np.where(np.arange(F) % 46 == 0, 0.26, 0.215), 0.06)
+    err = rng.random((F, n)) < perr[:, None]
+    y = np.where(err, (x + rng.integers(1, q, size=(F, n))) % q, x)
+    pr = np.full((F, n, q), 0.0)
+    for a in range(q):
+        pr[:, :, a] = np.where(y == a, 1 - 0.09, 0.09 / (q - 1))
+    if alg == "GF2P_WHT":
+        llr = np.round(np.log2(pr) * 16384).astype(np.int32)
+    else:
+        llr = np.log(pr)
+    dec = hip.Decoder(code, getattr(hip.ALG, alg), max_frames=F, early_exit=True)
+    it = 40
+    two = dec.decode(llr.reshape(F, n * q), s, it)
+    launches_two = dec.last_iterations
+    monkeypatch.setenv("LDPC_HIP_TWO_STAGE", "0")
+    one = dec.decode(llr.reshape(F, n * q), s, it)
+    monkeypatch.delenv("LDPC_HIP_TWO_STAGE")
+    slow = (one["iters"] > 16) | (one["status"] != 0)
+    print(f"{alg}: {int((one['status'] != 0).sum())} frames fail, {int(slow.sum())} slow, iterations "
+          f"{int(np.median(one['iters']))} median / {int(one['iters'].max())} max; passes: {launches_two}")
+    assert 0 < slow.sum() <= F // 16, "the case should leave a few (at most 1/16) slow frames"
+    for k in ("bits", "synd", "iters", "status"):
+        assert np.array_equal(one[k], two[k]), k
+    dec.close()
