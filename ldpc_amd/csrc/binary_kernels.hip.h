@@ -377,6 +377,21 @@ __device__ __forceinline__ int tab_gallag(const Tables &t, int x) {
   return t.fgallag[-x];
 }
 
+// Walks the rows of a check PF at a time: the PF rows are requested before the first is used, so a wavefront
+// has PF KiB in flight instead of one (a row per round trip left the two-sweep kernels latency-bound).
+template <int PF, typename Vec, typename RowFn, typename Body>
+__device__ __forceinline__ void cn_for_rows(int dc, RowFn row, Body body) {
+  for (int k0 = 0; k0 < dc; k0 += PF) {
+    Vec xb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+      if (k0 + u < dc) xb[u] = row(k0 + u);
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+      if (k0 + u < dc) body(k0 + u, xb[u]);
+  }
+}
+
 // Processes one check for one lane (V frames).  `row(k)` returns the k-th v2c
 // row of this check for this lane (LDS or global), `emit(k, vec)` stores c2v.
 template <typename T, int ALG, typename RowFn, typename EmitFn>
@@ -385,14 +400,14 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
   typedef typename MT<T>::vec vec;
   typedef typename MT<T>::acc acc;
   constexpr int V = MT<T>::V;
+  constexpr int PF = (ALG == ALG_SPA && sizeof(T) == 8) ? 4 : 8;   // (the binary64 sum-product bodies are register-hungry)
   unsigned sg = sbits;                 // bit v: s_j ^ XOR of v2c signs  (sgnprod, :163-166)
   if constexpr (ALG == ALG_MS || ALG == ALG_MSQ) {
     CnStateMin<acc> st[V];
     const acc big = ALG == ALG_MSQ ? (acc)Q88_CAP200 : (acc)200;
 #pragma unroll
     for (int v = 0; v < V; v++) st[v].init(big);
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    cn_for_rows<PF, vec>(dc, row, [&](int, const vec &x) {
 #pragma unroll
       for (int v = 0; v < V; v++) {
         const acc xv = (acc)x[v];
@@ -400,9 +415,8 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         st[v].add(neg ? -xv : xv);
         sg ^= (neg ? 1u : 0u) << v;
       }
-    }
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    });
+    cn_for_rows<PF, vec>(dc, row, [&](int k, const vec &x) {
       vec o;
 #pragma unroll
       for (int v = 0; v < V; v++) {
@@ -413,7 +427,7 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         o[v] = (T)(flip ? -mag : mag);
       }
       emit(k, o);
-    }
+    });
   } else if constexpr (ALG == ALG_SPA) {
     // test_code_B_float.c:159-178
     // logprod is summed in binary64 whatever the message type, as the reference does: the
@@ -422,8 +436,7 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
     double lp[V];
 #pragma unroll
     for (int v = 0; v < V; v++) lp[v] = 0;
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    cn_for_rows<PF, vec>(dc, row, [&](int, const vec &x) {
 #pragma unroll
       for (int v = 0; v < V; v++) {
         const acc xv = (acc)x[v];
@@ -431,9 +444,8 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         lp[v] = lp[v] + (double)spa_logtanh2(neg ? -xv : xv);
         sg ^= (neg ? 1u : 0u) << v;
       }
-    }
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    });
+    cn_for_rows<PF, vec>(dc, row, [&](int k, const vec &x) {
       vec o;
 #pragma unroll
       for (int v = 0; v < V; v++) {
@@ -444,13 +456,12 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         o[v] = (T)(flip ? -tout : tout);
       }
       emit(k, o);
-    }
+    });
   } else {   // ALG_TAB, test_code_B.c:195-213
     int lp[V];
 #pragma unroll
     for (int v = 0; v < V; v++) lp[v] = 0;
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    cn_for_rows<PF, vec>(dc, row, [&](int, const vec &x) {
 #pragma unroll
       for (int v = 0; v < V; v++) {
         const int xv = (int)x[v];
@@ -458,9 +469,8 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         lp[v] += tab_logtanh(tab, neg ? -xv : xv);
         sg ^= (neg ? 1u : 0u) << v;
       }
-    }
-    for (int k = 0; k < dc; k++) {
-      const vec x = row(k);
+    });
+    cn_for_rows<PF, vec>(dc, row, [&](int k, const vec &x) {
       vec o;
 #pragma unroll
       for (int v = 0; v < V; v++) {
@@ -471,7 +481,7 @@ __device__ __forceinline__ void cn_compute(int dc, unsigned sbits, const Tables 
         o[v] = (T)(flip ? -tout : tout);
       }
       emit(k, o);
-    }
+    });
   }
 }
 
@@ -552,6 +562,7 @@ __global__ __launch_bounds__(256) void cn_reload_kernel(
     const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
     unsigned par = sb;
     const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+#pragma unroll 8
     for (int k = 0; k < dc; k++) par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
     failacc |= par;
     cn_compute<T, ALG>(
@@ -596,20 +607,37 @@ __global__ __launch_bounds__(256) void cn_single_read_kernel(
     unsigned long long neg[V];
 #pragma unroll
     for (int v = 0; v < V; v++) { m1[v] = big; m2[v] = big; arg[v] = -1; neg[v] = 0; }
-    for (int k = 0; k < dc; k++) {
-      const vec x = rows[(size_t)k * 64];
-      par ^= hrow[(size_t)g.col_idx[p0 + k] * 64];
+    // PF rows (and the hard decisions of their variables) are requested before the first is used: one
+    // row per round trip, as this loop first was, left a wavefront with 1 KiB in flight -- 4 MB on the
+    // whole chip, where ~12 MB are needed to cover the memory latency at the bandwidth the pass could have
+    // (round 3: PEG-16000 Q8.8 check pass 4.3 -> see profiles/r03_twopass_*.json)
+    constexpr int PF = 8;
+    for (int k0 = 0; k0 < dc; k0 += PF) {
+      vec xb[PF];
+      unsigned hb[PF];
 #pragma unroll
-      for (int v = 0; v < V; v++) {
-        const acc xv = (acc)x[v];
-        const bool ng = xv < 0;
-        const acc a = ng ? -xv : xv;
-        neg[v] |= (unsigned long long)(ng ? 1u : 0u) << k;
-        sg ^= (ng ? 1u : 0u) << v;
-        const acc hi = a > m1[v] ? a : m1[v];
-        m2[v] = hi < m2[v] ? hi : m2[v];
-        if (a < m1[v]) { m1[v] = a; arg[v] = k; }
-      }
+      for (int u = 0; u < PF; u++)
+        if (k0 + u < dc) {
+          xb[u] = rows[(size_t)(k0 + u) * 64];
+          hb[u] = hrow[(size_t)g.col_idx[p0 + k0 + u] * 64];
+        }
+#pragma unroll
+      for (int u = 0; u < PF; u++)
+        if (k0 + u < dc) {
+          const int k = k0 + u;
+          par ^= hb[u];
+#pragma unroll
+          for (int v = 0; v < V; v++) {
+            const acc xv = (acc)xb[u][v];
+            const bool ng = xv < 0;
+            const acc a = ng ? -xv : xv;
+            neg[v] |= (unsigned long long)(ng ? 1u : 0u) << k;
+            sg ^= (ng ? 1u : 0u) << v;
+            const acc hi = a > m1[v] ? a : m1[v];
+            m2[v] = hi < m2[v] ? hi : m2[v];
+            if (a < m1[v]) { m1[v] = a; arg[v] = k; }
+          }
+        }
     }
     failacc |= par;
     for (int k = 0; k < dc; k++) {
