@@ -60,7 +60,7 @@ CODE = os.path.join(ROOT, "tests", "golden", "codes", "peg_16000_3_0.9.txt")
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0        # 256 CUs x 4 SIMD-32, wave64 instruction = 2 cycles, 2.4 GHz
 SEED = 0x1DBC0001
-COMMITTED_COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+COMMITTED_COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")
 
 
 def parse_args(argv=None):
@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true",
                     help="plumbing check without a GPU: gloo ranks, no decoding (tests/test_bench_launcher.py)")
     ap.add_argument("--save-counters", default=None,
-                    help="write the live counter passes to this JSON (the committed fallback, profiles/r02_counters.json)")
+                    help="write the live counter passes to this JSON (the committed fallback, profiles/r03_counters.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle spot-check of the last timed step")
     ap.add_argument("--verify-frames", type=int, default=32)
