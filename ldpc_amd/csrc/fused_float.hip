@@ -63,6 +63,7 @@ struct FfArgs {
   const uint16_t *vtabT;   // [VPT*CM][block]  (check << 5) | shift of its sign bit, per (thread, variable, edge)
   const uint32_t *maskT;   // [rounds][block]  real-slot bits in the kernel's mask layout (slot k at bit RM-1-k)
   const uint32_t *colP;    // binary64 register-cached kernel: packed slot addresses, [rounds][R2 / PK][block][PK]
+  const uint32_t *vtabW;   // wide-row kernel: one entry per edge of a thread's variables, [VPT / 2][LPG][block][4]
   // QG kernels (frames whose q0 does not fit beside the sums): the channel LLRs in placed order,
   // one row of var_words values per workgroup, in global memory (L2 / Infinity Cache resident)
   void *q0g;
@@ -938,6 +939,329 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg64_kernel(FfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide-row binary32 variant (round 3): frames whose channel LLRs do not fit in LDS beside the sums and
+// whose checks have 33 ... 48 slots -- 32000.2240.3.105: 128 KB of sums, row weights 42 / 43.  The plan of
+// the binary64 kernel above (q0 in registers, slot addresses from a shared L2-resident table), plus:
+//   LDS     sum[words] binary32; per check {min1, min2} (8 bytes), the signs of slots 0..31 (4 bytes), of
+//           slots 32..RM-1 (2 bytes) and the slot of min1 (1 byte), as four arrays: 15 bytes per check --
+//           a 16-byte record would put this code 272 bytes over the 160 KB
+//   VGPRs   q0 of the thread's VPT variables, the compressed state of its checks
+//   global  a.colP: slot addresses of the thread's checks, two per word (byte address in 17 bits | word
+//           index << 17), [round][chunk][thread][PK];
+//           a.vtabW: one 32-bit entry per edge of the thread's variables, [pair of variables][load][thread][4]:
+//           check (12 bits) | byte offset of the sign word that holds the edge's bit (14) | the edge's
+//           slot code (6: shift that brings its sign to bit 31, + 32 for slots >= 32); both tables are
+//           read a step ahead of their use with 16- / 8-byte loads and shared by every workgroup
+// The 16-bit sign words of two neighbouring checks share a 32-bit word; the variable pass reads that
+// word, and the entry's shift accounts for the half it wants (so every lane issues the same three LDS
+// reads per edge: b64, b32, u8).
+typedef float ff_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) ff_f2 lds_f2;
+
+typedef __amdgpu_buffer_rsrc_t ff_rsrc;
+__device__ __forceinline__ ff_rsrc ff_make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000 /* raw dwords, gfx9 */);
+}
+__device__ __forceinline__ fq_u4 ff_ld128(ff_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(fq_u4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ fq_u2 ff_ld64(ff_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(fq_u2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
+template <int HI>
+__device__ __forceinline__ lds_float *ff_wslot_ptr(unsigned packed) {
+  unsigned r;   // volatile: not hoisted out of the iteration loop
+  if (HI) asm volatile("v_lshrrev_b32 %0, 15, %1\n\tv_and_b32 %0, 0x1fffc, %0" : "=&v"(r) : "v"(packed));
+  else asm volatile("v_and_b32 %0, 0x1fffc, %1" : "=v"(r) : "v"(packed));
+  return (lds_float *)(unsigned long)r;
+}
+
+template <int CPT, int R2, int VPT, int CM, int LB, int MINW>
+__global__ __launch_bounds__(LB, MINW) void fused_ms_wide_kernel(FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ffsumw[];   // [words] sums, then the record arrays
+  constexpr int RM = 2 * R2;
+  static_assert(RM > 32 && RM <= 48 && R2 % 2 == 0, "two sign words, the second one of at most 16 bits");
+  constexpr int RB = RM - 32;                  // slots in the second sign word
+  static_assert(VPT % 2 == 0, "variables are walked in pairs");
+  constexpr int LPG = (2 * CM + 3) / 4;        // 16-byte loads of entries per pair of variables
+  constexpr int B = LB;
+  constexpr int PK = (R2 % 4 == 0) ? 4 : 2;    // packed slot-address words per load
+  constexpr int NCH = R2 / PK, CH = 2 * PK;    // chunks per check, slots per chunk
+  typedef unsigned ff_pk __attribute__((ext_vector_type(PK)));
+  const int tid = threadIdx.x;
+  ff_f2 *mag = (ff_f2 *)(ffsumw + a.words);                       // [m + 1] {min1, min2}   (words is even)
+  unsigned *sgL = (unsigned *)(mag + a.m + 1);                    // [m + 1] signs of slots 0..31 (slot k at bit 31-k)
+  unsigned short *sgH = (unsigned short *)(sgL + a.m + 1);        // [m + 1] signs of slots 32..RM-1 (slot k at bit RM-1-k)
+  unsigned char *argL = (unsigned char *)(sgH + a.m + 1);         // [m + 1] slot code of min1
+  int *frame_slot = (int *)(((size_t)(argL + a.m + 1) + 3) & ~(size_t)3);
+  const unsigned magbase = (unsigned)a.words * 4u;                // (the dynamic LDS starts at address 0: checked on the host)
+  const unsigned sgbase = magbase + (unsigned)(a.m + 1) * 8u;
+  const unsigned argbase = sgbase + (unsigned)(a.m + 1) * 6u;
+
+  bool has[CPT];
+#pragma unroll
+  for (int r = 0; r < CPT; r++) has[r] = r < a.rounds && r * B + tid < a.m;
+  // the three index tables through buffer loads: uniform base in a descriptor, the thread's column as one 32-bit
+  // lane offset, the row as a scalar offset (global loads cost a 64-bit vector add and an address pair per access)
+  const ff_rsrc rcol = ff_make_rsrc(a.colP, (unsigned)a.rounds * R2 * B * 4u);
+  const ff_rsrc rvt = ff_make_rsrc(a.vtabW, (unsigned)(VPT / 2) * LPG * B * 16u);
+  const ff_rsrc rmk = ff_make_rsrc(a.maskT, (unsigned)a.rounds * B * 8u);         // [rounds][B] real-slot bits of the two sign words
+  auto ld_pk = [&](unsigned soff) -> ff_pk {
+    if constexpr (PK == 4) return ff_ld128(rcol, (unsigned)tid * 16u, soff);
+    else return ff_ld64(rcol, (unsigned)tid * 8u, soff);
+  };
+  const bool wave_full = __ballot(has[CPT - 1]) != 0;
+  const bool vec_out = a.bits && (a.n & 7) == 0 && ((size_t)a.bits & 7) == 0;
+  const bool vec_in = (a.n & 3) == 0 && ((size_t)a.llr & 15) == 0;
+  const fq_u4 *pos8 = (const fq_u4 *)a.pos;
+
+  for (int i = a.dummy_base + tid; i < a.words; i += B) ffsumw[i] = 1e30f;     // pad slots: sign 0, never a minimum
+  for (int i = tid; i < a.var_words; i += B) ffsumw[i] = 0.0f;                  // (words that hold no variable)
+  if (tid == 0) {
+    ff_f2 none; none.x = 0.0f; none.y = 0.0f;                     // "no edge": message -0.0
+    mag[a.m] = none; sgL[a.m] = 0xffffffffu; sgH[a.m] = 0xffffu; argL[a.m] = 0xff;
+  }
+  int q_next = 0, q_lim = 0;
+  auto take_frame = [&]() {
+    if (q_next == q_lim) { q_next = atomicAdd(a.counter, a.chunk); q_lim = q_next + a.chunk; }
+    return q_next++;
+  };
+  if (tid == 0) *frame_slot = take_frame();
+  __syncthreads();
+  for (;;) {
+    const int frame = *frame_slot;
+    if (frame >= a.nframes) break;
+    int next_frame = 0;
+    if (tid == 0) next_frame = take_frame();
+    {
+      const size_t base = (size_t)frame * a.n;
+      if (a.dt == 1 && vec_in) {
+        typedef float ff_f4 __attribute__((ext_vector_type(4)));
+        const ff_f4 *p4 = (const ff_f4 *)((const float *)a.llr + base);
+        const fq_u2 *pos4 = (const fq_u2 *)a.pos;
+        for (int i = tid; i < (a.n >> 2); i += B) {
+          const ff_f4 v = __builtin_nontemporal_load(p4 + i);
+          const fq_u2 w = pos4[i];
+          ffsumw[w.x & 0xffffu] = v.x + 0.0f;
+          ffsumw[w.x >> 16] = v.y + 0.0f;
+          ffsumw[w.y & 0xffffu] = v.z + 0.0f;
+          ffsumw[w.y >> 16] = v.w + 0.0f;
+        }
+      } else if (a.dt == 1) {
+        const float *p = (const float *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) ffsumw[a.pos[i]] = __builtin_nontemporal_load(p + i) + 0.0f;
+      } else {
+        const double *p = (const double *)a.llr + base;
+        for (int i = tid; i < a.n; i += B) ffsumw[a.pos[i]] = (float)__builtin_nontemporal_load(p + i) + 0.0f;
+      }
+    }
+    float om1[CPT], om2[CPT];
+    unsigned oarg[CPT], osgA[CPT], osgB[CPT];
+    int sbit[CPT], par[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      om1[r] = om2[r] = 0.0f;
+      oarg[r] = 0u; osgA[r] = 0u; osgB[r] = 0u;
+      sbit[r] = (a.synd && has[r]) ? (a.synd[(size_t)frame * a.m + r * B + tid] & 1) : 0;
+      par[r] = 0;
+    }
+    if (tid == 0) { frame_slot[1] = 0; frame_slot[2] = 0; }   // flags of fq_block_or
+    __syncthreads();
+    // q0 of this thread's variables (the sums start as q0 + 0.0; the zero's sign never reaches a result)
+    float q0v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int w = tid + B * i;
+      q0v[i] = w < a.var_words ? ffsumw[w] : 0.0f;
+    }
+
+    int it_done = a.max_iter, ok = 0;
+    for (int t = 1; t <= a.max_iter + 1; t++) {
+      int bad = 0;
+      // (the tables are loop-invariant: a scalar offset that is opaque per iteration keeps their loads in the loop)
+      unsigned so = 0u;
+      asm volatile("" : "+s"(so));
+      auto check_pass = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          float m1 = (float)FF_CAP, m2 = (float)FF_CAP;
+          unsigned arg = 0u, pp = 0u;
+          // old signs leave at the top of their word while the new ones enter at the bottom
+          unsigned sgA = osgA[r], sgB = osgB[r] << (32 - RB);
+          unsigned long long ob[6];               // the slot of the previous minimum, one lane mask per bit (scalar registers)
+#pragma unroll
+          for (int b = 0; b < 6; b++) ob[b] = __ballot((oarg[r] >> b) & 1u);
+          ff_pk pk = ld_pk(so + (unsigned)((r * NCH) * B * PK * 4));
+          const fq_u2 allm = ff_ld64(rmk, (unsigned)tid * 8u, so + (unsigned)(r * B * 8));   // (re-read per iteration: two registers per check otherwise)
+#pragma unroll
+          for (int kc = 0; kc < RM; kc += CH) {
+            unsigned ix[PK];
+#pragma unroll
+            for (int j = 0; j < PK; j++) ix[j] = pk[j];
+            if (kc + CH < RM || r + 1 < NA) pk = ld_pk(so + (unsigned)((r * NCH + kc / CH + 1) * B * PK * 4));
+            float S[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) S[j] = (j & 1) ? *ff_wslot_ptr<1>(ix[j >> 1]) : *ff_wslot_ptr<0>(ix[j >> 1]);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+              const int k = kc + j;
+              if ((j & 1) == 0) pp = __builtin_amdgcn_bitop3_b32(pp, __float_as_uint(S[j]), __float_as_uint(S[j + 1]), 0x96);
+              unsigned long long in_k = (k & 1) ? ob[0] : ~ob[0];
+#pragma unroll
+              for (int b = 1; b < 6; b++) in_k &= ((k >> b) & 1) ? ob[b] : ~ob[b];
+              const float mo = ff_pick(om1[r], om2[r], in_k);                  // min2 in the slot of min1
+              if (k < 32) {
+                const float q = S[j] - __uint_as_float(FQ_ANDOR(sgA, 0x80000000u, __float_as_uint(mo)));   // :150
+                sgA = __builtin_amdgcn_alignbit(sgA, __float_as_uint(q), 31);
+                const float aq = __builtin_fabsf(q);
+                m2 = __builtin_amdgcn_fmed3f(m1, aq, m2);
+                const bool lt = aq < m1;
+                arg = lt ? (unsigned)k : arg;
+                m1 = lt ? aq : m1;
+              } else {
+                const float q = S[j] - __uint_as_float(FQ_ANDOR(sgB, 0x80000000u, __float_as_uint(mo)));
+                sgB = __builtin_amdgcn_alignbit(sgB, __float_as_uint(q), 31);
+                const float aq = __builtin_fabsf(q);
+                m2 = __builtin_amdgcn_fmed3f(m1, aq, m2);
+                const bool lt = aq < m1;
+                arg = lt ? (unsigned)k : arg;
+                m1 = lt ? aq : m1;
+              }
+            }
+            asm volatile("" : "+v"(pp), "+v"(m1), "+v"(m2), "+v"(arg), "+v"(sgA), "+v"(sgB));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const unsigned p = pp >> 31;
+          par[r] = (int)p;
+          bad |= has[r] ? ((int)p ^ sbit[r]) : 0;
+          const unsigned tot = (unsigned)sbit[r] ^ (unsigned)__popc(sgA) ^ (unsigned)__popc(sgB);
+          osgA[r] = (tot & 1u) ? (sgA ^ allm.x) : sgA;
+          osgB[r] = (tot & 1u) ? (sgB ^ allm.y) : sgB;
+          om1[r] = m1; om2[r] = m2; oarg[r] = arg;
+          asm volatile("" : "+v"(om1[r]), "+v"(om2[r]), "+v"(oarg[r]), "+v"(osgA[r]), "+v"(osgB[r]));
+          if (has[r]) {
+            const int j = r * B + tid;
+            ff_f2 mm; mm.x = om1[r]; mm.y = om2[r];
+            mag[j] = mm; sgL[j] = osgA[r]; sgH[j] = (unsigned short)osgB[r];
+            // the slot of min1 in the entries' code: slots < 32 by their number; slots >= 32 by 32 + the shift
+            // that brings their bit of the shared 32-bit word to bit 31 (odd checks sit in the high half)
+            const unsigned code = arg < 32u ? arg : arg + (unsigned)(64 - RM) - ((unsigned)(j & 1) << 4);
+            argL[j] = (unsigned char)code;
+          }
+        }
+      };
+      auto parity_only = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int r = 0; r < NA; r++) {
+          unsigned pp = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const ff_pk pk = ld_pk(so + (unsigned)((r * NCH + c) * B * PK * 4));
+#pragma unroll
+            for (int j = 0; j < PK; j++) {
+              const unsigned ix = pk[j];
+              const float s0 = *ff_wslot_ptr<0>(ix);
+              const float s1 = *ff_wslot_ptr<1>(ix);
+              pp = __builtin_amdgcn_bitop3_b32(pp, __float_as_uint(s0), __float_as_uint(s1), 0x96);
+            }
+          }
+          par[r] = (int)(pp >> 31);
+          bad |= has[r] ? (par[r] ^ sbit[r]) : 0;
+        }
+      };
+      if (t == a.max_iter + 1) {
+        if (wave_full) parity_only(std::integral_constant<int, CPT>{});
+        else parity_only(std::integral_constant<int, CPT - 1>{});
+      } else if (wave_full) check_pass(std::integral_constant<int, CPT>{});
+      else check_pass(std::integral_constant<int, CPT - 1>{});
+      const int any_bad = fq_block_or(bad, frame_slot + 1, t);
+      if (t > 1 && !any_bad) { it_done = t - 1; ok = 1; break; }
+      if (t == a.max_iter + 1) break;
+      // ---- variable pass: two variables (LPG 16-byte loads of entries) per step, the next step's entries
+      // requested before this step's records
+      fq_u4 en[LPG];
+#pragma unroll
+      for (int l = 0; l < LPG; l++) en[l] = ff_ld128(rvt, (unsigned)tid * 16u, so + (unsigned)(l * B * 16));
+#pragma unroll
+      for (int g = 0; g < VPT / 2; g++) {
+        unsigned ee[4 * LPG];
+#pragma unroll
+        for (int l = 0; l < LPG; l++) { ee[4 * l] = en[l].x; ee[4 * l + 1] = en[l].y; ee[4 * l + 2] = en[l].z; ee[4 * l + 3] = en[l].w; }
+        if (g + 1 < VPT / 2) {
+#pragma unroll
+          for (int l = 0; l < LPG; l++) en[l] = ff_ld128(rvt, (unsigned)tid * 16u, so + (unsigned)(((g + 1) * LPG + l) * B * 16));
+        }
+        float mgx[2][CM], mgy[2][CM];
+        unsigned sw[2][CM], ar[2][CM];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int kk = 0; kk < CM; kk++) {
+            const unsigned e = ee[u * CM + kk];
+            const unsigned cj = e & 0xfffu;
+            const ff_f2 mg = *(lds_f2 *)(unsigned long)(magbase + cj * 8u);
+            mgx[u][kk] = mg.x; mgy[u][kk] = mg.y;
+            sw[u][kk] = *(lds_uint *)(unsigned long)(sgbase + __builtin_amdgcn_ubfe(e, 12, 14));
+            ar[u][kk] = *(lds_u8 *)(unsigned long)(argbase + cj);
+            // (both minima are wanted in registers: left alone the select below becomes a second, dependent LDS read)
+            asm volatile("" : "+v"(mgx[u][kk]), "+v"(mgy[u][kk]));
+          }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int i = g * 2 + u;
+          const int w = tid + B * i;
+          float sum = q0v[i];
+#pragma unroll
+          for (int kk = 0; kk < CM; kk++) {
+            const unsigned code = ee[u * CM + kk] >> 26;
+            const unsigned m = (ar[u][kk] == code) ? __float_as_uint(mgy[u][kk]) : __float_as_uint(mgx[u][kk]);
+            sum = sum + __uint_as_float(FQ_ANDOR(sw[u][kk] << (code & 31u), 0x80000000u, m));
+          }
+          if (w < a.var_words) ffsumw[w] = sum + 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // bounds the records in flight (live registers)
+      }
+      __syncthreads();
+    }
+
+    if (vec_out) {
+      fq_u2 *o8 = (fq_u2 *)(a.bits + (size_t)frame * a.n);
+      const unsigned *us = (const unsigned *)ffsumw;
+      for (int i = tid; i < (a.n >> 3); i += B) {
+        const fq_u4 w = pos8[i];
+        fq_u2 b;
+        b.x = (us[w.x & 0xffffu] >> 31) | ((us[w.x >> 16] >> 31) << 8) | ((us[w.y & 0xffffu] >> 31) << 16) | ((us[w.y >> 16] >> 31) << 24);
+        b.y = (us[w.z & 0xffffu] >> 31) | ((us[w.z >> 16] >> 31) << 8) | ((us[w.w & 0xffffu] >> 31) << 16) | ((us[w.w >> 16] >> 31) << 24);
+        __builtin_nontemporal_store(b, o8 + i);
+      }
+    } else if (a.bits) {
+      uint8_t *o = a.bits + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = ffsumw[a.pos[i]] < 0.0f;
+    }
+    if (a.llr_out) {
+      float *o = a.llr_out + (size_t)frame * a.n;
+      for (int i = tid; i < a.n; i += B) o[i] = ffsumw[a.pos[i]];
+    }
+    if (a.sout) {
+#pragma unroll
+      for (int r = 0; r < CPT; r++)
+        if (has[r]) a.sout[(size_t)frame * a.m + r * B + tid] = (uint8_t)par[r];
+    }
+    if (tid == 0) {
+      if (a.iters) a.iters[frame] = it_done;
+      if (a.status) a.status[frame] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    if (tid == 0) *frame_slot = next_frame;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // the shapes the register-cached kernel is built for: {checks per thread, slot pairs, variables
 // per thread, edges per variable}
 #define FF_REG_SHAPES(X) \
@@ -953,6 +1277,11 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_reg64_kernel(FfArgs a) {
   X(2, 9, 10, 3, 512, 4)   /* 4095.737.3 */ \
   X(1, 7, 6, 3, 256, 4)    /* 1057.244.3 */ \
   X(1, 3, 2, 3, 128, 4)    /* 204.33.484 */
+
+// the wide-row binary32 kernel (33 ... 48 slots per check)
+#define FF_WIDE_SHAPES(X) \
+  X(3, 22, 32, 3, 1024, 4) /* 32000.2240.3.105, 16 wavefronts */ \
+  X(3, 22, 42, 3, 768, 3)  /* 32000.2240.3.105, 12 wavefronts of 168 registers */
 
 namespace {
 
@@ -986,13 +1315,20 @@ FfKern ff_reg64_lookup(int cpt, int r2, int vpt, int cm, int block) {
   return nullptr;
 }
 
+FfKern ff_wide_lookup(int cpt, int r2, int vpt, int cm, int block) {
+#define FF_X(C, R, V, M, LB, MW) if (cpt == C && r2 == R && vpt == V && cm == M && block == LB) return fused_ms_wide_kernel<C, R, V, M, LB, MW>;
+  FF_WIDE_SHAPES(FF_X)
+#undef FF_X
+  return nullptr;
+}
+
 template <typename T>
 struct FusedFloatEngine : Engine {
   ldpc_opts opts{};
   int n = 0, m = 0, rmax = 0, cmax = 0, RM = 0, NW = 1;
   int block = 0, rounds = 0, wg_per_cu = 1, num_cu = 256;
   size_t lds = 0;
-  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter, d_vtabT, d_maskT, d_colP;
+  DevBuf d_colT, d_realT, d_vtab, d_pos, d_counter, d_vtabT, d_maskT, d_colP, d_vtabW;
   LdsSchedule sched;
   FfKern kern = nullptr;
   bool use_reg = false;
@@ -1006,6 +1342,8 @@ struct FusedFloatEngine : Engine {
   static size_t lds_bytes_qg(int words, int m, int nw) {
     return sizeof(T) * ((size_t)words + 2 * (size_t)(m + 1)) + 4 * (size_t)nw * (m + 1) + (size_t)(m + 1) + 24;
   }
+  // the wide-row binary32 kernel: sums, 15 bytes per check, the frame word and the exit flags
+  static size_t lds_bytes_wide(int words, int m) { return 4 * (size_t)words + 15 * (size_t)(m + 1) + 3 + 16; }
   bool qg = false;
   DevBuf d_q0g;
   void *ws_q0g = nullptr;
@@ -1015,7 +1353,8 @@ struct FusedFloatEngine : Engine {
     if (c.q != 2 || c.n > 65000 || c.rmax > 64 || c.rmax < 1 || c.cmax > 32 || c.m > 8192) return false;
     const int nw = (2 * ((c.rmax + 1) / 2) + 31) / 32;
     return lds_bytes(c.n + 64 + FF_NDUMMY, c.n + 64, c.m, nw) + 1024 <= 160 * 1024 ||
-           lds_bytes_qg(c.n + 64 + FF_NDUMMY, c.m, nw) + 256 <= 160 * 1024;
+           lds_bytes_qg(c.n + 64 + FF_NDUMMY, c.m, nw) + 256 <= 160 * 1024 ||
+           (sizeof(T) == 4 && nw == 2 && lds_bytes_wide(c.n + FF_NDUMMY, c.m) <= 160 * 1024);
   }
   size_t llr_elems_per_frame() const override { return (size_t)n; }
 
@@ -1135,6 +1474,84 @@ struct FusedFloatEngine : Engine {
         break;
       }
     }
+    // Second choice, binary32 with 33 ... 48 slots per check: the wide-row kernel (q0 in registers, 15 bytes of
+    // record per check, both index tables from L2).
+    if (!use_reg && !F64 && env_reg && NW == 2 && RM <= 48 && m <= 4094 && cmax >= 1) {
+      for (int W : {16, 12}) {
+        if (env_w && W != env_w) continue;
+        const int B = W * 64;
+        LdsSchedule sc;
+        if (ldpc_build_lds_schedule(c, B, RM, FF_NDUMMY, optimise != 0, sc)) continue;
+        if (sc.words & 1) sc.words++;                                     // (8-byte alignment of the pairs)
+        const int vpt = 2 * ((sc.var_words + 2 * B - 1) / (2 * B));
+        FfKern k = ff_wide_lookup(sc.rounds, RM / 2, vpt, cmax, B);
+        if (getenv("LDPC_HIP_DEBUG"))
+          fprintf(stderr, "fused float (wide rows): shape {%d checks/thread, %d slot pairs, %d variables/thread, %d edges/variable, %d threads}, %d words: %s\n",
+                  sc.rounds, RM / 2, vpt, cmax, B, sc.words, k ? "built" : "no kernel");
+        if (!k) continue;
+        hipFuncAttributes fa;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void *)k));
+        // the kernel addresses its dynamic LDS from 0; a slot is a 15-bit word index / a 17-bit byte address; an
+        // edge's sign word is found by a 14-bit byte offset
+        const size_t need_lds = lds_bytes_wide(sc.words, m);
+        if (fa.sharedSizeBytes != 0 || sc.words > 32767 || 6 * (size_t)(m + 1) > 16383 || need_lds > 160 * 1024) continue;
+        const int R2 = RM / 2, PK = (R2 % 4 == 0) ? 4 : 2, RB = RM - 32;
+        std::vector<uint32_t> cp((size_t)sc.rounds * R2 * B, 0u), mk((size_t)sc.rounds * B * 2, 0u);
+        std::vector<int> slot_of_edge(c.E(), -1);
+        for (int j = 0; j < m; j++) {
+          const int r = j / B, t = j % B;
+          for (int kk = 0; kk < RM; kk++) {
+            const int w = sc.colT[((size_t)r * RM + kk) * B + t];
+            if (w >= sc.dummy_base) continue;
+            // the kernel's masks: slot k < 32 at bit 31-k of the first word, slot k >= 32 at bit RM-1-k of the second
+            if (kk < 32) mk[((size_t)r * B + t) * 2] |= 1u << (31 - kk);
+            else mk[((size_t)r * B + t) * 2 + 1] |= 1u << (RM - 1 - kk);
+            for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++)
+              if (sc.pos[c.col_idx[e]] == w) slot_of_edge[e] = kk;
+          }
+        }
+        for (int r = 0; r < sc.rounds; r++)
+          for (int k2 = 0; k2 < R2; k2++)
+            for (int t = 0; t < B; t++) {
+              const uint32_t lo = sc.colT[((size_t)r * RM + 2 * k2) * B + t], hi = sc.colT[((size_t)r * RM + 2 * k2 + 1) * B + t];
+              cp[(((size_t)r * (R2 / PK) + k2 / PK) * B + t) * PK + k2 % PK] = (lo * 4u) | (hi << 17);
+            }
+        std::vector<int> inv(sc.var_words, -1);
+        for (int v = 0; v < n; v++) inv[sc.pos[v]] = v;
+        const int lpg = (2 * cmax + 3) / 4;                               // 16-byte loads per pair of variables
+        std::vector<uint32_t> vw((size_t)(vpt / 2) * lpg * B * 4, (uint32_t)m | ((uint32_t)(4 * m) << 12));   // "no edge": record m, code 0
+        bool lost = false;
+        for (int t = 0; t < B; t++)
+          for (int i = 0; i < vpt; i++) {
+            const int w = t + B * i;
+            if (w >= sc.var_words || inv[w] < 0) continue;
+            const int v = inv[w];
+            for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++) {
+              const int e = c.edge_of[c.col_ptr[v] + kk];
+              const int s = slot_of_edge[e], j = row_of[e];
+              if (s < 0) { lost = true; continue; }
+              // sign word: slots < 32 in sgL[j]; the others in the 32-bit word that holds sgH[j] (high half for odd j)
+              const uint32_t sa = s < 32 ? 4u * (uint32_t)j : 4u * (uint32_t)(m + 1) + 4u * (uint32_t)(j >> 1);
+              const uint32_t code = s < 32 ? (uint32_t)s : (uint32_t)(s + 64 - RM - 16 * (j & 1));
+              const int idx = (i & 1) * cmax + kk;                        // within the pair's 4 * lpg entries
+              vw[(((size_t)(i / 2) * lpg + idx / 4) * B + t) * 4 + idx % 4] = (uint32_t)j | (sa << 12) | (code << 26);
+            }
+          }
+        if (lost || RB > 16) continue;
+        sched = sc;
+        kern = k; use_reg = true; qg = false;
+        block = B; rounds = sc.rounds;
+        lds = need_lds;
+        if ((rc = d_colP.ensure(cp.size() * 4))) return rc;
+        if ((rc = d_vtabW.ensure(vw.size() * 4))) return rc;
+        if ((rc = d_maskT.ensure(mk.size() * 4))) return rc;
+        HIPCHK(hipMemcpy(d_colP.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_vtabW.p, vw.data(), vw.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_maskT.p, mk.data(), mk.size() * 4, hipMemcpyHostToDevice));
+        wg_per_cu = 1;
+        break;
+      }
+    }
     if (!use_reg) {
     // generic kernel: up to 16 wavefronts, every wavefront with the same number of checks
     int W = std::min(16, need);
@@ -1248,6 +1665,7 @@ struct FusedFloatEngine : Engine {
     a.vtabT = d_vtabT.as<uint16_t>();
     a.maskT = d_maskT.as<uint32_t>();
     a.colP = d_colP.as<uint32_t>();
+    a.vtabW = d_vtabW.as<uint32_t>();
     long grid = (long)num_cu * wg_per_cu;
     if (grid > nframes) grid = nframes;
     a.chunk = (int)std::max<long>(1, std::min<long>(std::min<long>(4096 / n, nframes / (grid * 16)), 16));
