@@ -86,6 +86,47 @@ __global__ __launch_bounds__(256) void blocked_kernel(const u4 *__restrict__ a, 
   if (MODE == READ && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = 1;
 }
 
+// the two-pass decoders' own shape: every wavefront (ROWL = 64 lanes) or workgroup (ROWL = 256) reads NR rows of
+// ROWL x 16 bytes that lie far apart (a variable's edges), and writes them back -- rows in a scrambled order, so
+// that neighbouring wavefronts do not walk neighbouring rows
+template <int ROWL, int NR>
+__global__ __launch_bounds__(256) void rows_kernel(u4 *__restrict__ b, size_t nrows) {
+  const size_t units = nrows / NR;
+  const size_t nunit = ROWL == 64 ? (size_t)gridDim.x * 4 : gridDim.x;
+  size_t unit = ROWL == 64 ? (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+  const int lane = ROWL == 64 ? (threadIdx.x & 63) : threadIdx.x;
+  for (; unit < units; unit += nunit) {
+    u4 v[NR];
+    size_t row[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      row[k] = ((unit * NR + k) * 2654435761ull) % nrows;     // (odd multiplier: a permutation when nrows is a power of two)
+      v[k] = b[row[k] * ROWL + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) b[row[k] * ROWL + lane] = v[k] + 1u;
+  }
+}
+
+template <int ROWL, int NR>
+static double run_rows(u4 *b, size_t bytes, int blocks) {
+  size_t nrows = 1;
+  while (nrows * 2 * ROWL * 16 <= bytes) nrows *= 2;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((rows_kernel<ROWL, NR>), dim3(blocks), dim3(256), 0, 0, b, nrows);
+  CHECK(hipDeviceSynchronize());
+  const int reps = 10;
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((rows_kernel<ROWL, NR>), dim3(blocks), dim3(256), 0, 0, b, nrows);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return (double)nrows * ROWL * 16 * 2 * reps / (ms * 1e-3) / 1e9;
+}
+
 template <int MODE, int UNROLL, bool NT, bool BLOCKED = false>
 static double run(const u4 *a, u4 *b, size_t bytes, int blocks, unsigned *sink) {
   const size_t n16 = bytes / 16;
@@ -145,6 +186,13 @@ int main(int argc, char **argv) {
   for (int wg : {8, 32, 128}) {
     BROW(READ, 4, false); BROW(READ, 4, true); BROW(WRITE, 4, false); BROW(COPY, 4, false); BROW(COPY, 4, true);
     BROW(RMW, 4, false); BROW(RMW, 4, true); BROW(RMW, 1, false);
+  }
+  printf("# scattered rows, read then written back in place (the two-pass decoders' access shape): rows of 1 KiB per wavefront / 4 KiB per workgroup, 3 or 8 rows in flight\n");
+  for (int wg : {8, 16, 32}) {
+    printf("rows 1 KiB x3  %6d %10.1f\n", wg, run_rows<64, 3>(b, bytes, cus * wg));
+    printf("rows 1 KiB x8  %6d %10.1f\n", wg, run_rows<64, 8>(b, bytes, cus * wg));
+    printf("rows 4 KiB x3  %6d %10.1f\n", wg, run_rows<256, 3>(b, bytes, cus * wg));
+    printf("rows 4 KiB x8  %6d %10.1f\n", wg, run_rows<256, 8>(b, bytes, cus * wg));
   }
   printf("# best: read %.0f, write %.0f, copy %.0f, in-place %.0f GB/s = %.2f / %.2f / %.2f / %.2f of the 8 TB/s peak\n", best[0], best[1],
          best[2], best[3], best[0] / 8000, best[1] / 8000, best[2] / 8000, best[3] / 8000);
