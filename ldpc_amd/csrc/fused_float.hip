@@ -1495,6 +1495,10 @@ struct FusedFloatEngine : Engine {
         // edge's sign word is found by a 14-bit byte offset
         const size_t need_lds = lds_bytes_wide(sc.words, m);
         if (fa.sharedSizeBytes != 0 || sc.words > 32767 || 6 * (size_t)(m + 1) > 16383 || need_lds > 160 * 1024) continue;
+        if (optimise) ldpc_place_variable_pass_wide(c, sc, &vconf_before, &vconf_after);
+        if (getenv("LDPC_HIP_DEBUG"))
+          fprintf(stderr, "fused float (wide rows): variable-pass extra LDS cycles %ld -> %ld of %d group reads\n", vconf_before, vconf_after,
+                  ((sc.var_words + 63) / 64) * 2 * cmax);
         const int R2 = RM / 2, PK = (R2 % 4 == 0) ? 4 : 2, RB = RM - 32;
         std::vector<uint32_t> cp((size_t)sc.rounds * R2 * B, 0u), mk((size_t)sc.rounds * B * 2, 0u);
         std::vector<int> slot_of_edge(c.E(), -1);

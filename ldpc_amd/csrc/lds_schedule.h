@@ -25,3 +25,5 @@ int ldpc_build_lds_schedule(const ldpc_code &c, int block, int RM, int ndummy, b
 // the fused float kernel's variable pass meet few bank conflicts; rewrites sc.pos / sc.colT.
 // *before / *after: modelled extra LDS cycles per iteration.
 void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after);
+// the same for the wide-row kernel's 8-byte {min1, min2} pairs (two 32-lane groups per ds_read_b64, 32 bank pairs)
+void ldpc_place_variable_pass_wide(const ldpc_code &c, LdsSchedule &sc, long *before, long *after);

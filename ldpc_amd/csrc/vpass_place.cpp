@@ -13,15 +13,21 @@
 // LDS cycle when its 16 records sit in 16 different bank quads (record index mod 16); random
 // ranks give ~3.  Local search over swaps of two variables of one bank: cost = sum over
 // groups and edges of the busiest quad.  Returns the extra LDS cycles left (and before).
-void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after) {
+//
+// wide = true: the wide-row kernel's layout instead -- {min1, min2} pairs of 8 bytes read with ds_read_b64, which is
+// served in two groups of 32 lanes (lanes 0-31, 32-63), one LDS cycle each when the 32 records sit in 32 different
+// bank pairs (record index mod 32).
+static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after, const bool wide) {
+  const int QM = wide ? 32 : 16;          // bank classes of a record
   std::vector<int> row_of(c.E());
   for (int j = 0; j < c.m; j++)
     for (int e = c.row_ptr[j]; e < c.row_ptr[j + 1]; e++) row_of[e] = j;
-  const int W = sc.var_words, CM = std::max(1, c.cmax), NT = ((W + 63) / 64) * 4;
+  const int W = sc.var_words, CM = std::max(1, c.cmax), NT = ((W + 63) / 64) * (wide ? 2 : 4);
   std::vector<int> occ(W, -1);
   for (int v = 0; v < c.n; v++) occ[sc.pos[v]] = v;
-  auto tuple_of = [](int w) {
+  auto tuple_of = [wide](int w) {
     const int l = w & 63, b = l & 31;
+    if (wide) return (w >> 6) * 2 + (l >> 5);
     const bool a = b <= 3 || (b >= 12 && b <= 15) || (b >= 20 && b <= 27);
     return (w >> 6) * 4 + (l >> 5) * 2 + (a ? 0 : 1);
   };
@@ -30,11 +36,11 @@ void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before,
   std::vector<int8_t> quad((size_t)c.n * CM, -1);
   for (int v = 0; v < c.n; v++)
     for (int kk = 0; kk < c.col_ptr[v + 1] - c.col_ptr[v]; kk++)
-      quad[(size_t)v * CM + kk] = (int8_t)(row_of[c.edge_of[c.col_ptr[v] + kk]] & 15);
+      quad[(size_t)v * CM + kk] = (int8_t)(row_of[c.edge_of[c.col_ptr[v] + kk]] & (QM - 1));
   auto cost = [&](int t) {
     int total = 0;
     for (int kk = 0; kk < CM; kk++) {
-      int cnt[16] = {0}, mx = 0;
+      int cnt[32] = {0}, mx = 0;
       for (int w : members[t]) {
         const int v = occ[w];
         if (v < 0) continue;
@@ -51,18 +57,18 @@ void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before,
   // simulated annealing on swaps of two variables of one bank.  Energy per (group, edge):
   // 16 * (busiest quad - 1) + number of surplus entries (the second term guides the search
   // where the first is flat).  Counts are kept per (group, edge, quad).
-  std::vector<uint8_t> cnt((size_t)NT * CM * 16, 0);
+  std::vector<uint8_t> cnt((size_t)NT * CM * QM, 0);
   auto energy_of = [&](int t, int kk) {
-    const uint8_t *q = &cnt[((size_t)t * CM + kk) * 16];
+    const uint8_t *q = &cnt[((size_t)t * CM + kk) * QM];
     int mx = 0, surplus = 0;
-    for (int i = 0; i < 16; i++) { mx = std::max<int>(mx, q[i]); surplus += q[i] > 1 ? q[i] - 1 : 0; }
-    return 16 * (mx > 0 ? mx - 1 : 0) + surplus;
+    for (int i = 0; i < QM; i++) { mx = std::max<int>(mx, q[i]); surplus += q[i] > 1 ? q[i] - 1 : 0; }
+    return QM * (mx > 0 ? mx - 1 : 0) + surplus;
   };
   auto add = [&](int t, int v, int d) {
     if (v < 0) return;
     for (int kk = 0; kk < CM; kk++) {
       const int q = quad[(size_t)v * CM + kk];
-      if (q >= 0) cnt[((size_t)t * CM + kk) * 16 + q] = (uint8_t)(cnt[((size_t)t * CM + kk) * 16 + q] + d);
+      if (q >= 0) cnt[((size_t)t * CM + kk) * QM + q] = (uint8_t)(cnt[((size_t)t * CM + kk) * QM + q] + d);
     }
   };
   std::vector<int> tw(W);
@@ -82,7 +88,7 @@ void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before,
     add(t, occ[w], -1); add(t2, occ[w2], -1);
     add(t, occ[w2], +1); add(t2, occ[w], +1);
     const int e1 = energy_t(t) + energy_t(t2);
-    const int budget = (int)(12 * (moves - it) / moves);
+    const int budget = (int)((wide ? 24 : 12) * (moves - it) / moves);
     if (e1 - e0 <= budget - (int)(rnd() % (uint32_t)(budget + 1))) {
       std::swap(occ[w], occ[w2]);
     } else {
@@ -103,3 +109,10 @@ void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before,
     if (occ[w] >= 0) sc.pos[occ[w]] = (uint16_t)w;
 }
 
+
+void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after) {
+  place_variable_pass(c, sc, before, after, false);
+}
+void ldpc_place_variable_pass_wide(const ldpc_code &c, LdsSchedule &sc, long *before, long *after) {
+  place_variable_pass(c, sc, before, after, true);
+}
