@@ -1115,26 +1115,38 @@ __device__ __forceinline__ T ingest_convert(InT x) {
 }
 
 // in [nframes][n] (frame-major, as the callers of dec() hold q0) ->
-// q0 [slab][n][64] vec.  Block = 256 threads, tile = 32 variables x one slab.
+// q0 [slab][n][64] vec.  Block = 256 threads, tile = 32 variables x one slab, transposed through LDS.
+// The tile's row pitch puts the 32 variables a half-wavefront writes for one frame into 32 different banks
+// (pitch = one element more than a multiple of 64 dwords; the two frames of a wavefront are four apart, so
+// they do not share a dword either): with the 16-byte-aligned pitch of rounds 1-2 the column writes met 4-way
+// bank conflicts and the pass ran at 1.8 TB/s.  Rows are then only 4-byte aligned and are read back as dwords.
 template <typename InT, typename T, int ALG>
 __global__ __launch_bounds__(256) void ingest_kernel(const InT *__restrict__ in, int nframes, int n,
                                                      typename MT<T>::vec *__restrict__ q0) {
   typedef typename MT<T>::vec vec;
   constexpr int V = MT<T>::V;
   constexpr int SF = 64 * V;
-  constexpr int LD = SF + V;   // 16-byte pad keeps rows 16-B aligned
-  __shared__ __attribute__((aligned(16))) T tile[32 * LD];
+  constexpr int LD = SF + (sizeof(T) < 4 ? 4 / (int)sizeof(T) : 1);
+  static_assert(sizeof(vec) == 16, "a lane's row is four dwords");
+  __shared__ __attribute__((aligned(16))) T tile[32 * LD + 8];
   const int b = blockIdx.y;
   const int i0 = blockIdx.x * 32;
   const int tid = threadIdx.x;
   {
     const int ii = tid & 31;
     const int i = i0 + ii;
-    for (int f = tid >> 5; f < SF; f += 8) {
-      const long frame = (long)b * SF + f;
-      T val = (T)0;
-      if (frame < nframes && i < n) val = ingest_convert<InT, T, ALG>(in[frame * n + i]);
-      tile[ii * LD + f] = val;
+    // eight loads in flight per lane (one load, one LDS store at a time left the pass latency-bound: 89 % of the
+    // wave cycles waiting)
+    static_assert(SF % 64 == 0, "eight frames per step, eight steps per batch");
+    for (int f0 = (tid >> 6) + 4 * ((tid >> 5) & 1); f0 < SF; f0 += 64) {
+      InT raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const long frame = (long)b * SF + f0 + 8 * u;
+        raw[u] = (frame < nframes && i < n) ? in[frame * n + i] : (InT)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) tile[ii * LD + f0 + 8 * u] = ingest_convert<InT, T, ALG>(raw[u]);
     }
   }
   __syncthreads();
@@ -1142,7 +1154,10 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT *__restrict__ in,
     const int lane = tid & 63;
     for (int r = tid >> 6; r < 32; r += 4) {
       const int i = i0 + r;
-      if (i < n) q0[((size_t)b * n + i) * 64 + lane] = *reinterpret_cast<const vec *>(&tile[r * LD + lane * V]);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(&tile[r * LD + lane * V]);
+      uint4 w;
+      w.x = src[0]; w.y = src[1]; w.z = src[2]; w.w = src[3];
+      if (i < n) q0[((size_t)b * n + i) * 64 + lane] = __builtin_bit_cast(vec, w);
     }
   }
 }
