@@ -194,3 +194,5 @@ Engine *ldpc_make_fused_float_engine(int prec, const ldpc_code &c);
 // chain_q88.hip: frame-resident Q8.8 min-sum for staircase (IRA / DVB-S2) codes too large for the
 // fused decoder's LDS sums; init() returns LDPC_ERR_UNSUPPORTED for codes it does not serve
 Engine *ldpc_make_chain_q88_engine();
+// the staircase binary32 min-sum decoder (stair_f32.hip); init() returns LDPC_ERR_UNSUPPORTED for codes it does not serve
+Engine *ldpc_make_stair_f32_engine(const ldpc_opts &o);

@@ -1165,9 +1165,27 @@ extern "C" int ldpc_decoder_create(const ldpc_code *c, const ldpc_opts *opts, ld
         // any other value (or LDPC_HIP_FUSED=0) selects the two-pass HBM engine
         const bool f32 = opts->alg == LDPC_ALG_MINSUM_F32;
         if (opts->cn_variant == 0 && fmode != 0) {
+          // (LDPC_HIP_CHAIN=2: the staircase decoder wherever it applies -- tests on small codes)
+          if (const char *ce2 = getenv("LDPC_HIP_CHAIN"); f32 && ce2 && atoi(ce2) == 2) {
+            d->eng.reset(ldpc_make_stair_f32_engine(d->opts));
+            if (d->eng && d->eng->init(d->code, d->opts) == LDPC_OK) { *out = d.release(); return LDPC_OK; }
+            d->eng.reset();
+          }
           d->eng.reset(ldpc_make_fused_float_engine(f32 ? 4 : 8, *c));
           if (d->eng && d->eng->init(d->code, d->opts) != LDPC_OK) d->eng.reset();
           if (d->eng) { *out = d.release(); return LDPC_OK; }
+          // binary32 on an accumulator-chain code whose frame fits neither LDS layout (DVB-S2 long frames): the
+          // staircase decoder of stair_f32.hip; LDPC_HIP_CHAIN=0 turns it off
+          const char *ce = getenv("LDPC_HIP_CHAIN");
+          if (f32 && !(ce && atoi(ce) == 0)) {
+            d->eng.reset(ldpc_make_stair_f32_engine(d->opts));
+            if (d->eng) {
+              const int rc = d->eng->init(d->code, d->opts);
+              if (rc == LDPC_OK) { *out = d.release(); return LDPC_OK; }
+              d->eng.reset();
+              if (rc != LDPC_ERR_UNSUPPORTED) return rc;
+            }
+          }
         }
         if (f32) d->eng.reset(new BinaryEngine<float, ALG_MS>);
         else d->eng.reset(new BinaryEngine<double, ALG_MS>);
