@@ -22,7 +22,9 @@
 //     LDS read, add, write: one writer per variable and step).  Columns list their checks in rising order
 //     (checked on the host), so "round by round" IS column-slot order, except for two checks of one
 //     variable in the same round: the later one waits for a second (rarely third) step of that round.
-//     DVB-S2 0.5: 9 527 of the 32 400 information bits have such a pair, 32 a triple; 66 steps per iteration.
+//     DVB-S2 0.5: 9 527 of the 32 400 information bits have such a pair, 32 a triple.  In the steps after the first
+//     a check has at most one slot in turn (the host spreads them: three extra steps per round on DVB-S2), so such a
+//     step is one LDS read, one add, one write per lane and a barrier.
 //
 // Slots of a check: 0 = staircase variable shared with the previous check, 1 = the one shared with the next
 // check (or a private weight-1 variable: DVB-S2's last parity bit), 2..7 = up to six LDS variables.
@@ -44,12 +46,13 @@ namespace {
 #define SF_VPT 32           /* LDS variables per thread (q0 in registers) */
 
 struct StairArgs {
-  const fq_u4 *tab;          // [J] per check: six 16-bit LDS word numbers, flags, step numbers of the six slots
+  const fq_u4 *tab;          // [J] per check: six 16-bit LDS word numbers, flags
+  const fq_u4 *tab2;         // [J][2] per check, for the rebuild of the sums: six words of step 0, three of steps 1..3 (trash word where none), their slots
   const uint16_t *pos;       // [n] variable -> LDS word, or 0x8000 | check whose right-hand variable it is
   const uint16_t *rightvar;  // [J] the variable to the right of check j (0xffff: none)
-  const uint8_t *nsteps;     // [rounds] steps of round r in the ordered rebuild of the sums
+  unsigned long long nsteps; // steps of round r in the ordered rebuild of the sums, minus one: two bits per round
   float *q0p;                // [grid][J] channel values of the right-hand variables
-  uint32_t *rec;             // [grid][2][J][3] records {min1, min2, signs | slot of min1 << 8}
+  uint32_t *rec;             // [grid][2][J][3] records {min1, min2, signs (slot k at bit 7 - k) | slot of min1 << 8}
   int n, m, J, rounds, words, dummy_base, var_words;
   int nframes, max_iter;
   const void *llr;
@@ -62,13 +65,21 @@ struct StairArgs {
   float *llr_out;
   int *counter;
   int chunk;
+  int ablate;                // timing experiments (LDPC_HIP_STAIR_ABLATE; results wrong): 1 = no rebuild rounds, 2 = no check pass
 };
 
-// flags of a check (tab row, halfword 6): bit 0 = has a left staircase variable, bit 1 = has a right-hand variable,
-// bit 2 = that variable is private (weight 1), bits 3..8 = which of the six LDS slots hold a variable
-enum { SF_LEFT = 1, SF_RIGHT = 2, SF_PRIV = 4 };
+// flags of a check (tab row, halfword 6): bits 0..7 = which slots hold a variable, slot k at bit 7 - k (the layout of
+// a record's sign bits: v_alignbit shifts them in from the right), bit 8 = the right-hand variable is private (weight 1).
+// Halfword 7: the step (0..2) of each LDS slot in the rebuild of the sums, two bits per slot, 3 = no variable.
+enum { SF_LEFT = 0x80, SF_RIGHT = 0x40, SF_PRIV = 0x100 };
 
 typedef __amdgpu_buffer_rsrc_t sf_rsrc;
+typedef __attribute__((address_space(3))) float sf_lds_float;
+__device__ __forceinline__ float ff_pick32(float a, float b, unsigned long long take_b) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(take_b));
+  return r;
+}
 typedef unsigned sf_u3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ sf_rsrc sf_make_rsrc(const void *base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000 /* raw dwords, gfx9 */);
@@ -87,10 +98,15 @@ __device__ __forceinline__ void sf_st96(sf_u3 v, sf_rsrc r, unsigned voff, unsig
   __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3, v), r, (int)voff, (int)soff, 0);
 }
 
-// message of a record to the variable in slot k: min2 where k is the slot of min1, the sign from bit k
+// A barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight (vmcnt(0)):
+// in the rebuild loop that is the prefetch of the round after next, and the wait put a full memory latency into
+// every round (44 of the 84 us of an iteration).
+__device__ __forceinline__ void sf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// message of a record to the variable in slot k: min2 where k is the slot of min1, the sign from bit 7 - k
 __device__ __forceinline__ float sf_msg(sf_u3 rec, unsigned k) {
   const unsigned mag = ((rec.z >> 8) & 15u) == k ? rec.y : rec.x;
-  return __uint_as_float(mag | (((rec.z >> k) & 1u) << 31));
+  return __uint_as_float(FQ_ANDOR(rec.z << (24u + k), 0x80000000u, mag));
 }
 
 template <int B>
@@ -99,17 +115,17 @@ __global__ __launch_bounds__(B) void stair_f32_kernel(StairArgs a) {
   constexpr int NWV = B / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int J = a.J;
-  unsigned long long *hardbits = (unsigned long long *)(sfs + ((a.words + 1) & ~1));   // [rounds][NWV]
+  // [words] sums | [64] trash words (a word per lane for slots not in turn; the host's tables name them) | hard decisions | frame word, flags
+  unsigned long long *hardbits = (unsigned long long *)(sfs + a.words + 64);            // [rounds][NWV]   (words is even)
   int *frame_slot = (int *)(hardbits + a.rounds * NWV);
   float *q0p = a.q0p + (size_t)blockIdx.x * J;
   uint32_t *recbase = a.rec + (size_t)blockIdx.x * 2 * J * 3;
   const sf_rsrc rtab = sf_make_rsrc(a.tab, (unsigned)J * 16u);
+  const sf_rsrc rtab2 = sf_make_rsrc(a.tab2, (unsigned)J * 32u);
   const sf_rsrc rq0 = sf_make_rsrc(q0p, (unsigned)J * 4u);
   const sf_rsrc rrec = sf_make_rsrc(recbase, (unsigned)J * 24u);       // both sets: set s starts at s * J * 12
-  const unsigned long long lanes_below = lane ? (~0ull >> (64 - lane)) : 0ull;
-  (void)lanes_below;
 
-  for (int i = a.dummy_base + tid; i < a.words; i += B) sfs[i] = 1e30f;     // pad slots: sign 0, never a minimum
+  for (int i = a.dummy_base + tid; i < a.words + 64; i += B) sfs[i] = 1e30f;     // pad slots: sign 0, never a minimum
   for (int i = tid; i < a.var_words; i += B) sfs[i] = 0.0f;                 // (words that hold no variable)
   int q_next = 0, q_lim = 0;
   auto take_frame = [&]() {
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(B) void stair_f32_kernel(StairArgs a) {
       const unsigned oldset = (unsigned)((t - 1) & 1) * (unsigned)J * 12u, newset = (unsigned)(t & 1) * (unsigned)J * 12u;
       const bool first = t == 1, last = t == a.max_iter + 1;
       int bad = 0;
-      for (int r = 0; r < a.rounds; r++) {
+      for (int r = 0; r < ((a.ablate & 2) ? 0 : a.rounds); r++) {
         const int j = r * B + tid;
         const unsigned jo = (unsigned)j;
         const fq_u4 row = sf_ld128(rtab, jo * 16u, 0u);
@@ -184,40 +200,55 @@ __global__ __launch_bounds__(B) void stair_f32_kernel(StairArgs a) {
         const float q0R = sf_ld32f(rq0, jo * 4u, 0u);
         const float q0L = sf_ld32f(rq0, (jo ? jo - 1u : 0u) * 4u, 0u);
         const unsigned flags = row.w & 0xffffu;
-        // the six LDS slots (pads point at dummy words: 1e30)
-        float S[8], q[8];
+        // the six LDS slots (pads point at dummy words: 1e30, sign 0, never a minimum)
+        float S[8];
         S[2] = sfs[row.x & 0xffffu]; S[3] = sfs[row.x >> 16];
         S[4] = sfs[row.y & 0xffffu]; S[5] = sfs[row.y >> 16];
         S[6] = sfs[row.z & 0xffffu]; S[7] = sfs[row.z >> 16];
+        // the slot of the check's previous minimum, one lane mask per bit (scalar registers): which lanes take min2 in
+        // slot k is then an AND on the scalar unit
+        unsigned long long ob[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) ob[b] = __ballot((own.z >> (8 + b)) & 1u);
+        auto own_msg = [&](int k) {
+          unsigned long long in_k = (k & 1) ? ob[0] : ~ob[0];
+          in_k &= (k & 2) ? ob[1] : ~ob[1];
+          in_k &= (k & 4) ? ob[2] : ~ob[2];
+          const float mo = ff_pick32(__uint_as_float(own.x), __uint_as_float(own.y), in_k);
+          return __uint_as_float(FQ_ANDOR(own.z << (24 + k), 0x80000000u, __float_as_uint(mo)));
+        };
         // the staircase variables: (q0 + the earlier check's message) + the later check's, the column's order (:146-148)
-        const float cl = sf_msg(own, 0u), cr = sf_msg(own, 1u);
-        S[0] = (q0L + sf_msg(lft, 1u)) + cl;
-        S[1] = (flags & SF_PRIV) ? q0R + cr : (q0R + cr) + sf_msg(rgt, 0u);
-        unsigned par = 0u, sg = 0u, arg = 0u;      // par: H*bits of this check (:200-203)
+        float co[8];
+        co[0] = own_msg(0); co[1] = own_msg(1);
+        const float S0 = (q0L + sf_msg(lft, 1u)) + co[0];
+        const float S1a = q0R + co[1], S1 = (flags & SF_PRIV) ? S1a : S1a + sf_msg(rgt, 0u);
+        S[0] = (flags & SF_LEFT) ? S0 : 1e30f;
+        S[1] = (flags & SF_RIGHT) ? S1 : 1e30f;
+        unsigned pacc = 0u, sg = 0u, arg = 0u;
         float m1 = SF_CAP, m2 = SF_CAP;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          const bool real = k == 0 ? (flags & SF_LEFT) != 0 : k == 1 ? (flags & SF_RIGHT) != 0 : ((flags >> (k + 1)) & 1u) != 0;
-          const float Sn = real ? S[k] + 0.0f : 1e30f;      // (-0.0 -> +0.0: the sign bit is then "sum < 0", :190)
-          par ^= __float_as_uint(Sn) >> 31;
-          q[k] = Sn - sf_msg(own, (unsigned)k);             // :150
-          sg |= (__float_as_uint(q[k]) >> 31) << k;
-          const float aq = __builtin_fabsf(q[k]);
-          m2 = __builtin_amdgcn_fmed3f(m1, aq, m2);         // :168-176
+          S[k] = S[k] + 0.0f;                                 // (-0.0 -> +0.0: the sign bit is then "sum < 0", :190)
+          pacc ^= __float_as_uint(S[k]);
+          if (k >= 2) co[k] = own_msg(k);
+          const float q = S[k] - co[k];                       // :150
+          sg = __builtin_amdgcn_alignbit(sg, __float_as_uint(q), 31);
+          const float aq = __builtin_fabsf(q);
+          m2 = __builtin_amdgcn_fmed3f(m1, aq, m2);           // :168-176
           const bool lt = aq < m1;
           arg = lt ? (unsigned)k : arg;
           m1 = lt ? aq : m1;
-          S[k] = Sn;
         }
-        if (j < a.m) bad |= (int)(par ^ ((sbits >> r) & 1u));
+        const unsigned par = pacc >> 31;                      // H*bits of this check (:200-203)
+        const unsigned sb = (sbits >> r) & 1u;
+        if (j < a.m) bad |= (int)(par ^ sb);
         if (!last) {
           // signs of the new messages: the product of the others' signs and the syndrome bit (:163-166, :178)
-          const unsigned realmask = (flags & 3u) | (((flags >> 3) & 63u) << 2);
-          const unsigned tot = (((sbits >> r) & 1u) ^ (unsigned)__popc(sg)) & 1u;
-          const unsigned nsg = (tot ? ~sg : sg) & realmask;
+          const unsigned tot = (sb ^ (unsigned)__popc(sg)) & 1u;
+          const unsigned nsg = (tot ? ~sg : sg) & (flags & 0xffu);
           sf_u3 nr;
           nr.x = __float_as_uint(m1); nr.y = __float_as_uint(m2); nr.z = nsg | (arg << 8);
-          if (j < J) sf_st96(nr, rrec, jo * 12u, newset);
+          sf_st96(nr, rrec, jo * 12u, newset);
         }
         // hard decision of the right-hand variable (bit `lane` of the wavefront's word)
         const unsigned long long hb = __ballot((flags & SF_RIGHT) && S[1] < 0.0f);
@@ -236,20 +267,56 @@ __global__ __launch_bounds__(B) void stair_f32_kernel(StairArgs a) {
         if (w < a.var_words) sfs[w] = q0v[i];
       }
       __syncthreads();
-      for (int r = 0; r < a.rounds; r++) {
+      // (the barriers of the steps keep the wavefronts in lock step, so nothing hides a load's latency but distance:
+      // a round's table rows and record are requested two rounds ahead)
+      struct StepIn { fq_u4 ra, rb; sf_u3 nr; };
+      auto fetch2 = [&](int r) {
+        StepIn in;
         const unsigned jo = (unsigned)(r * B + tid);
-        const fq_u4 row = sf_ld128(rtab, jo * 16u, 0u);
-        const sf_u3 nr = sf_ld96(rrec, jo * 12u, newset);
-        const unsigned flags = row.w & 0xffffu, modes = row.w >> 16;
-        const int ns = a.nsteps[r];
-        unsigned wk[6];
-        wk[0] = row.x & 0xffffu; wk[1] = row.x >> 16; wk[2] = row.y & 0xffffu; wk[3] = row.y >> 16; wk[4] = row.z & 0xffffu; wk[5] = row.z >> 16;
-        for (int s = 0; s < ns; s++) {
+        in.ra = sf_ld128(rtab2, jo * 32u, 0u);
+        in.rb = sf_ld128(rtab2, jo * 32u, 16u);
+        in.nr = sf_ld96(rrec, jo * 12u, newset);
+        return in;
+      };
+      auto round_steps = [&](const StepIn &cur, int r) {
+        const sf_u3 nr = cur.nr;
+        const int ns = 1 + (int)((a.nsteps >> (2 * r)) & 3ull);
+        // step 0: every slot whose check is the first of its variable in this round (the others, and empty slots,
+        // point at the lane's trash word): six reads, six adds, six writes, no branches
+        {
+          unsigned ad[6];
+          float v[6];
+          ad[0] = (cur.ra.x & 0xffffu) * 4u; ad[1] = (cur.ra.x >> 16) * 4u; ad[2] = (cur.ra.y & 0xffffu) * 4u;
+          ad[3] = (cur.ra.y >> 16) * 4u; ad[4] = (cur.ra.z & 0xffffu) * 4u; ad[5] = (cur.ra.z >> 16) * 4u;
 #pragma unroll
-          for (int k = 0; k < 6; k++)
-            if (((flags >> (k + 3)) & 1u) && ((modes >> (2 * k)) & 3u) == (unsigned)s) sfs[wk[k]] = sfs[wk[k]] + sf_msg(nr, (unsigned)(k + 2));
-          __syncthreads();
+          for (int k = 0; k < 6; k++) v[k] = *(sf_lds_float *)(unsigned long)ad[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) *(sf_lds_float *)(unsigned long)ad[k] = v[k] + sf_msg(nr, (unsigned)(k + 2));
+          sf_lds_barrier();
         }
+        // steps 1..3: a later check of a variable already served in this round; at most one slot per lane and step
+        for (int s = 1; s < ns; s++) {
+          const unsigned wsel = s == 1 ? (cur.ra.w & 0xffffu) : s == 2 ? (cur.ra.w >> 16) : (cur.rb.x & 0xffffu);
+          const unsigned k = (cur.rb.x >> (16 + 3 * (s - 1))) & 7u;
+          const unsigned ad = wsel * 4u;
+          const float v = *(sf_lds_float *)(unsigned long)ad;
+          *(sf_lds_float *)(unsigned long)ad = v + sf_msg(nr, k);
+          sf_lds_barrier();
+        }
+      };
+      // three buffers in rotation, no copies between them (a copy needs its data: the wait for the newest load)
+      const int nr_rounds = (a.ablate & 1) ? 0 : a.rounds;
+      auto clampr = [&](int r) { return r < a.rounds ? r : a.rounds - 1; };
+      StepIn b0 = fetch2(0), b1 = fetch2(clampr(1)), b2;
+      for (int r = 0; r < nr_rounds; r += 3) {
+        b2 = fetch2(clampr(r + 2));
+        round_steps(b0, r);
+        if (r + 1 >= nr_rounds) break;
+        b0 = fetch2(clampr(r + 3));
+        round_steps(b1, r + 1);
+        if (r + 2 >= nr_rounds) break;
+        b1 = fetch2(clampr(r + 4));
+        round_steps(b2, r + 2);
       }
     }
 
@@ -283,7 +350,8 @@ __global__ __launch_bounds__(B) void stair_f32_kernel(StairArgs a) {
 struct StairF32Engine : Engine {
   int n = 0, m = 0, block = 0, rounds = 0, J = 0, num_cu = 256, words = 0, dummy_base = 0, var_words = 0;
   size_t lds = 0;
-  DevBuf d_tab, d_pos, d_rightvar, d_nsteps, d_q0p, d_rec, d_counter;
+  DevBuf d_tab, d_tab2, d_pos, d_rightvar, d_q0p, d_rec, d_counter;
+  unsigned long long nsteps_packed = 0;
   void (*kern)(StairArgs) = nullptr;
 
   size_t llr_elems_per_frame() const override { return (size_t)n; }
@@ -363,8 +431,9 @@ struct StairF32Engine : Engine {
       return LDPC_ERR_UNSUPPORTED;
     }
     words = sc.words; dummy_base = sc.dummy_base; var_words = sc.var_words;
-    lds = (size_t)((words + 1) & ~1) * 4 + (size_t)rounds * (block / 64) * 8 + 16;
-    if (lds > 160 * 1024 || words > 0x7fff || var_words > SF_VPT * block) {
+    if (words & 1) words++;
+    lds = (size_t)words * 4 + 64 * 4 + (size_t)rounds * (block / 64) * 8 + 16;
+    if (lds > 160 * 1024 || words + 64 > 0xffff || var_words > 0x7fff || var_words > SF_VPT * block) {
       ldpc_set_error("staircase binary32 decoder: the variables outside the staircase do not fit in LDS");
       return LDPC_ERR_UNSUPPORTED;
     }
@@ -374,19 +443,24 @@ struct StairF32Engine : Engine {
     std::vector<uint16_t> rightvar((size_t)J, 0xffff);
     for (int j = 0; j < m; j++)
       if (right[j] >= 0) { pos[right[j]] = (uint16_t)(0x8000 | j); rightvar[j] = (uint16_t)right[j]; }
-    // slot of every edge to an LDS variable, and its step within the round: the s-th check of its variable in that round
-    std::vector<uint16_t> tab((size_t)J * 8, 0);
+    // slot of every edge to an LDS variable; for the rebuild, its step within the round: 0 for the first check of its
+    // variable in that round, else a later step -- after the variable's previous check, and such that a check has at
+    // most one slot in each of the steps 1..3
+    std::vector<uint16_t> tab((size_t)J * 8, 0), tab2((size_t)J * 16, 0);
     std::vector<uint8_t> nsteps((size_t)rounds, 1);
-    std::vector<int> last_round(nl, -1), seen(nl, 0);
+    std::vector<int> last_round(nl, -1), last_step(nl, 0);
     for (int j = 0; j < J; j++) {
       const int r = j / block, t = j % block;
-      uint16_t *row = &tab[(size_t)j * 8];
-      unsigned flags = 0, modes = 0;
+      uint16_t *row = &tab[(size_t)j * 8], *row2 = &tab2[(size_t)j * 16];
+      const uint16_t trashw = (uint16_t)(words + (t & 63));
+      unsigned flags = 0, ks = 0;
       if (j < m) {
         if (j >= 1 && right[j - 1] >= 0 && !priv[j - 1]) flags |= SF_LEFT;
         if (right[j] >= 0) flags |= SF_RIGHT;
         if (right[j] >= 0 && priv[j]) flags |= SF_PRIV;
       }
+      for (int k = 0; k < 9; k++) row2[k] = trashw;
+      int free_step = 1;
       for (int k = 0; k < 6; k++) {
         const int w = sc.colT[((size_t)r * 6 + k) * block + t];
         row[k] = (uint16_t)w;
@@ -396,29 +470,35 @@ struct StairF32Engine : Engine {
         for (int e = vc.row_ptr[j]; e < vc.row_ptr[j + 1]; e++)
           if (sc.pos[vc.col_idx[e]] == w) lv = vc.col_idx[e];
         if (lv < 0) { ldpc_set_error("staircase binary32 decoder: schedule lost an edge"); return LDPC_ERR_FORMAT; }
-        flags |= 1u << (k + 3);
-        if (last_round[lv] != r) { last_round[lv] = r; seen[lv] = 0; }
-        const int step = seen[lv]++;
-        if (step > 2) { ldpc_set_error("staircase binary32 decoder: more than three checks of a variable in one round"); return LDPC_ERR_UNSUPPORTED; }
-        modes |= (unsigned)step << (2 * k);
+        flags |= 0x80u >> (k + 2);
+        if (last_round[lv] != r) { last_round[lv] = r; last_step[lv] = 0; row2[k] = (uint16_t)w; continue; }
+        const int step = std::max(free_step, last_step[lv] + 1);
+        if (step > 3) { ldpc_set_error("staircase binary32 decoder: too many checks of one variable in a round"); return LDPC_ERR_UNSUPPORTED; }
+        free_step = step + 1;
+        last_step[lv] = step;
+        row2[5 + step] = (uint16_t)w;
+        ks |= (unsigned)(k + 2) << (3 * (step - 1));
         nsteps[r] = (uint8_t)std::max<int>(nsteps[r], step + 1);
       }
       row[6] = (uint16_t)flags;
-      row[7] = (uint16_t)modes;
+      row[7] = 0;
+      row2[9] = (uint16_t)ks;
     }
     int rc;
     if ((rc = d_tab.ensure(tab.size() * 2))) return rc;
+    if ((rc = d_tab2.ensure(tab2.size() * 2))) return rc;
     if ((rc = d_pos.ensure(pos.size() * 2))) return rc;
     if ((rc = d_rightvar.ensure(rightvar.size() * 2))) return rc;
-    if ((rc = d_nsteps.ensure(nsteps.size()))) return rc;
     if ((rc = d_counter.ensure(256))) return rc;
     HIPCHK(hipMemcpy(d_tab.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tab2.p, tab2.data(), tab2.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_pos.p, pos.data(), pos.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_rightvar.p, rightvar.data(), rightvar.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_nsteps.p, nsteps.data(), nsteps.size(), hipMemcpyHostToDevice));
+    nsteps_packed = 0;
+    for (int r = 0; r < rounds; r++) nsteps_packed |= (unsigned long long)(nsteps[r] - 1) << (2 * r);
     hipFuncAttributes fa;
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)kern));
-    if (lds + fa.sharedSizeBytes > 160 * 1024) {
+    if (fa.sharedSizeBytes != 0 || lds > 160 * 1024) {   // (the kernel addresses its dynamic LDS from 0)
       ldpc_set_error("staircase binary32 decoder: frame does not fit in LDS");
       return LDPC_ERR_UNSUPPORTED;
     }
@@ -440,9 +520,10 @@ struct StairF32Engine : Engine {
     HIPCHK(hipMemsetAsync(counter, 0, 4, st));
     StairArgs a;
     a.tab = d_tab.as<fq_u4>();
+    a.tab2 = d_tab2.as<fq_u4>();
     a.pos = d_pos.as<uint16_t>();
     a.rightvar = d_rightvar.as<uint16_t>();
-    a.nsteps = d_nsteps.as<uint8_t>();
+    a.nsteps = nsteps_packed;
     a.q0p = q0p; a.rec = rec;
     a.n = n; a.m = m; a.J = J; a.rounds = rounds; a.words = words; a.dummy_base = dummy_base; a.var_words = var_words;
     a.nframes = nframes; a.max_iter = max_iter;
@@ -450,6 +531,8 @@ struct StairF32Engine : Engine {
     a.bits = bits; a.iters = iters_out; a.sout = sout; a.status = status; a.llr_out = llr_out;
     a.counter = counter;
     a.chunk = (int)std::max<long>(1, std::min<long>(nframes / (grid * 16), 16));
+    a.ablate = 0;
+    if (const char *e = getenv("LDPC_HIP_STAIR_ABLATE")) a.ablate = atoi(e);
     prof_cur_frames = nframes;
     prof_begin(K_FUSED, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, a);
