@@ -187,6 +187,10 @@ int ldpc_decode_batch_device(ldpc_decoder *d, int nframes, const void *llr, int 
  *     (channel values of the staircase variables, two sets of minima rows: 320 KiB per workgroup
  *     for dvb_H_0.5) -- the grid is CAPPED at the workgroups whose rows fit (102 of 256 for that
  *     code), so throughput is below ldpc_decode_batch_device()'s there; results are the same;
+ *   staircase binary32 min-sum (MINSUM_F32 on DVB-S2 long frames):  the queue head plus 28 bytes per check
+ *     (padded to whole rounds of 1 024) and workgroup -- channel values of the staircase variables and two
+ *     sets of 12-byte check records: 896 KiB per workgroup for dvb_H_0.5 -- the grid is capped the same
+ *     way (36 of 256 workgroups);
  *   two-pass decoders:  edge-message store, hard decisions and per-frame state,
  *     64 * ceil(nframes / SF) * (16 n + 16 E + n + 2 m + ...) bytes (SF = 512 frames for int16
  *     messages, 256 for binary32 / int32, 128 for binary64), which must fit the 32 MiB; their

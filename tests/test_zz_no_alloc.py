@@ -104,6 +104,10 @@ CASES = [
     # staircase frame-resident kernel: its per-workgroup rows (R * block * 10 B = 320 KiB for this code) come out of
     # the scratch, so the grid is capped at the 102 workgroups whose rows fit 32 MiB
     ("dvb_H_0.5.txt", "MINSUM_Q88", {}, 300, 9, 0.05),
+    # wide-row binary32 kernel (q0 in registers: the queue head is all it takes from the scratch)
+    ("32000.2240.3.105.txt", "MINSUM_F32", {}, 150, 9, 0.0005),
+    # staircase binary32 decoder: 28 bytes per check and workgroup (896 KiB for this code): 36 workgroups fit
+    ("dvb_H_0.5.txt", "MINSUM_F32", {}, 100, 9, 0.04),
 ]
 
 
