@@ -3,7 +3,7 @@
 //
 // dec() of test_code_min_sum_B.c:137-208 in binary32 (the arithmetic of fused_float.hip's kernels: every
 // floating-point operation is the reference's, on the same operands in the same order, so bits, iteration
-// counts, syndromes and posterior sums equal the oracle's binary32 twin bit for bit).  The difficulty is the
+// counts, syndromes and posterior sums equal those of a binary32 transcription of the reference, bit for bit: tests/).  The difficulty is the
 // order: the reference adds a variable's messages in column-slot order (:146-148) and floating-point sums
 // are not associative, so chain_q88.hip's integer trick (fold new - old into the LDS sums with atomics, in
 // any order) is not available, and fused_float.hip's variable pass needs every check's record within reach
