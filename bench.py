@@ -331,6 +331,15 @@ CONFIG_LEGS = [
     dict(id="configs[3]", code="32000.2240.3.105.txt", alg="MINSUM_Q88", dt="I16", channel="BSC_EXACT", p=13.0 / 32000,
          iters=200, frames=1 << 16, batch=1 << 16, fused=True, b=2,
          what="32000.2240.3.105 Q8.8 min-sum, exactly 13 flips per frame (FER floor region), <= 200 iterations, syndrome early exit"),
+    dict(id="configs[3]/MINSUM_F32", code="32000.2240.3.105.txt", alg="MINSUM_F32", dt="F32", channel="BSC_EXACT", p=13.0 / 32000,
+         iters=200, frames=1 << 16, batch=1 << 16, fused=True, b=4,
+         what="32000.2240.3.105 binary32 min-sum (wide-row frame-resident kernel), exactly 13 flips per frame, <= 200 iterations, "
+              "syndrome early exit"),
+    dict(id="configs[2]/MINSUM_F32", code="dvb_H_0.5.txt", alg="MINSUM_F32", dt="F32", channel="AWGN", ebn0=2.4, iters=50,
+         frames=4096, batch=4096, fused=True, kernel="stair_f32", b=4,
+         what="DVB-S2 rate 1/2 binary32 min-sum (staircase frame-resident kernel), Eb/N0 = 2.4 dB, <= 50 iterations, early exit",
+         note="bounded by the HBM traffic of its per-workgroup record rows (14.3 MB per frame at 10 iterations, "
+              "profiles/r03_stair_f32_counters.txt), not by vector issue"),
     dict(id="configs[4]", code="q4.sp.9000.6000.4500.1", alg="GF2P_WHT", dt="I32", channel=None, iters=10, frames=2048,
          batch=2048, fused=False, b=4,
          what="GF(4) q4.sp.9000.6000.4500.1 Walsh-Hadamard check nodes, 10 iterations executed, random priors resident"),
@@ -351,6 +360,8 @@ def run_config_leg(i, local_rank, child=False):
                            early_exit=leg["channel"] is not None)
     dt = getattr(DT, leg["dt"])
     rec = {"config": leg["id"], "workload": leg["what"], "alg": leg["alg"], "frames": frames, "iterations": leg["iters"]}
+    if "note" in leg:
+        rec["note"] = leg["note"]
     if leg["channel"] is None:                              # GF(4): resident random priors, all iterations executed
         dev = torch.device("cuda", local_rank)
         gen = torch.Generator(device=dev)
@@ -425,7 +436,7 @@ def config_counters(args):
         if not leg["fused"]:
             continue
         child = [sys.executable, os.path.abspath(__file__), "--config-child", str(i)]
-        c, src = live_counters(args, "fused_", child=child, passes=CONFIG_PMC_PASS)
+        c, src = live_counters(args, leg.get("kernel", "fused_"), child=child, passes=CONFIG_PMC_PASS)
         out[i] = (c, src)
     return out
 
