@@ -803,6 +803,161 @@ __global__ __launch_bounds__(256) LDPC_CN_REG_WAVES void cn_reg_kernel(
   if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
 }
 
+// Binary64 sum-product for row weights 17 ... 64 in the tanh domain (round 3; see spa_tanh_half64 and the
+// product branch of cn_reg_kernel, which holds a whole check of up to 16 rows).  A heavier check is walked in
+// chunks of CH rows:
+//   1. chunks 0 .. n-2: rows read, t_k = tanh(|v2c_k| / 2) evaluated, only the chunk's product kept;
+//   2. the last chunk: read, evaluated and KEPT (t_k in the rows' registers, prefix products beside them);
+//   3. F_c = the product of all OTHER chunks' products; the kept chunk is finished: message of row k =
+//      2 atanh((F_c * prefix_k) * suffix_k), written over the row;
+//   4. chunks 0 .. n-2 again: rows read a second time, t_k evaluated a second time, finished the same way.
+// (2 - 1/n) tanh evaluations and one 2 atanh per edge value, where the two-sweep reload kernel spends two
+// log tanh and one 2 atanh(exp): about 155 vector instructions per edge value instead of 270.  Hazards as in
+// the reference: a row whose own t is 0 gets NaN (-inf - -inf), the others of its check 0; a product of 1
+// gives +inf.
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cn_spa64_chunk_kernel(
+    Graph g, int nslab, MT<double>::vec *__restrict__ msg, const uint8_t *__restrict__ hard,
+    const uint8_t *__restrict__ synd, uint32_t *__restrict__ fail) {
+  typedef MT<double>::vec vec;
+  constexpr int V = MT<double>::V;
+  constexpr int NCH = 64 / CH;           // chunks of the heaviest check served
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id_uniform();
+  const int nw = (int)((gridDim.x * blockDim.x) >> 6);
+  const int b = w % nslab;
+  const int c0 = w / nslab;
+  const int wps = nw / nslab;
+  unsigned failacc = 0;
+  if (c0 >= wps) return;
+  for (int j = c0; j < g.m; j += wps) {
+    const int p0 = g.row_ptr[j];
+    const int dc = g.row_ptr[j + 1] - p0;
+    vec *rows = msg + ((size_t)b * g.E + p0) * 64 + lane;
+    const unsigned sb = synd ? synd[((size_t)b * g.m + j) * 64 + lane] : 0u;
+    unsigned par = sb, sg = sb;
+    const uint8_t *hrow = hard + (size_t)b * g.n * 64 + lane;
+    const int nch = (dc + CH - 1) / CH;
+    double P[NCH][V];                    // chunk products
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+      for (int v = 0; v < V; v++) P[c][v] = 1.0;
+    vec x[CH];
+    // rows k0 .. k0+cnt-1 -> x (all requested before the first is used); the hard decisions' parity on the first visit
+    auto load = [&](int k0, int cnt, bool first) {
+#pragma unroll
+      for (int u = 0; u < CH; u++)
+        if (u < cnt) {
+          x[u] = rows[(size_t)(k0 + u) * 64];
+          if (first) par ^= hrow[(size_t)g.col_idx[p0 + k0 + u] * 64];
+        }
+    };
+    // x: v2c -> t = tanh(|v2c| / 2) with the row's sign kept in the sign bit of t (t >= 0, so the bit is free);
+    // returns the chunk's product; signs into sg on the first visit
+    auto forward = [&](int cnt, bool first, double prod[V]) {
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        double run = 1.0;
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+          if (u < cnt) {
+            const double xv = x[u][v];
+            const bool neg = xv < 0;
+            const double t = spa_tanh_half64(neg ? -xv : xv);
+            run = run * t;
+            if (first) sg ^= (neg ? 1u : 0u) << v;
+            x[u][v] = __hiloint2double(__double2hiint(t) | (neg ? (int)0x80000000 : 0), __double2loint(t));
+          }
+        prod[v] = run;
+      }
+    };
+    // x: t -> the outgoing messages, stored.  The prefix products are rebuilt here from the kept t (a multiplication
+    // per row: cheaper than 2 * CH registers held across the other chunks' work)
+    auto finish = [&](int k0, int cnt, const double F[V]) {
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        double pre[CH];
+        double run = F[v];
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+          if (u < cnt) {
+            pre[u] = run;
+            run = run * __hiloint2double(__double2hiint(x[u][v]) & 0x7fffffff, __double2loint(x[u][v]));
+          }
+        double suf = 1.0;
+#pragma unroll
+        for (int u = CH - 1; u >= 0; u--)
+          if (u < cnt) {
+            const unsigned hi = (unsigned)__double2hiint(x[u][v]);
+            const double t = __hiloint2double((int)(hi & 0x7fffffffu), __double2loint(x[u][v]));
+            double tout = spa_atanh2_64(pre[u] * suf);
+            tout = t == 0.0 ? __builtin_nan("") : tout;            // the reference's -inf - (-inf)
+            suf = suf * t;
+            const unsigned flip = ((hi >> 31) ^ (sg >> v)) & 1u;   // sgnprod != the row's own sign
+            x[u][v] = __hiloint2double(__double2hiint(tout) ^ (int)(flip << 31), __double2loint(tout));
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < CH; u++)
+        if (u < cnt) rows[(size_t)(k0 + u) * 64] = x[u];
+    };
+    // 1. products of the chunks before the last
+    for (int c = 0; c + 1 < nch; c++) {
+      load(c * CH, CH, true);
+      double pr[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) pr[v] = 1.0;
+#pragma unroll
+      for (int u = 0; u < CH; u++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          const double xv = x[u][v];
+          const bool neg = xv < 0;
+          pr[v] = pr[v] * spa_tanh_half64(neg ? -xv : xv);
+          sg ^= (neg ? 1u : 0u) << v;
+        }
+#pragma unroll
+      for (int cc = 0; cc < NCH; cc++)
+        if (cc == c) {
+#pragma unroll
+          for (int v = 0; v < V; v++) P[cc][v] = pr[v];
+        }
+    }
+    // 2. the last chunk, kept
+    const int lastc = nch - 1, lcnt = dc - lastc * CH;
+    load(lastc * CH, lcnt, true);
+    failacc |= par;
+    double plast[V];
+    forward(lcnt, true, plast);
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++)
+      if (cc == lastc) {
+#pragma unroll
+        for (int v = 0; v < V; v++) P[cc][v] = plast[v];
+      }
+    // 3. / 4. every chunk finished with the product of the others
+    for (int c = nch - 1; c >= 0; c--) {
+      double F[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) F[v] = 1.0;
+#pragma unroll
+      for (int cc = 0; cc < NCH; cc++)
+        if (cc != c && cc < nch) {
+#pragma unroll
+          for (int v = 0; v < V; v++) F[v] = F[v] * P[cc][v];
+        }
+      if (c != nch - 1) {
+        load(c * CH, CH, false);
+        double dummy[V];
+        forward(CH, false, dummy);
+      }
+      finish(c * CH, c == nch - 1 ? lcnt : CH, F);
+    }
+  }
+  if (failacc) atomicOr(&fail[b * 64 + lane], failacc);
+}
+
 // Table sum-product with both tables in LDS (engine.h: kTabc* has the format, tables.cpp builds and
 // checks the image).  The gathers of the other kernels go to 32 MiB of tables through the vector L1:
 // 64 requests per wavefront instruction, three instructions per edge and frame.  Here a workgroup

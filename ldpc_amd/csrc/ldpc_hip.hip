@@ -267,7 +267,8 @@ struct BinaryEngine : Engine {
     //   0 auto, 1 LDS staged through registers, 2 two-pass reload, 3 register
     //   resident (min-sum, rmax <= 32), 4 LDS staged by global->LDS DMA, 5 single read
     //   with compressed per-frame state (min-sum, rmax <= 64), 6 both tables in LDS (table
-    //   sum-product; the default there, 4 when the tables do not have the structure it needs)
+    //   sum-product; the default there, 4 when the tables do not have the structure it needs), 7 chunked
+    //   tanh-domain kernel (binary64 sum-product, row weights 17 ... 64; the default there)
     cn_variant = o.cn_variant;
     if (const char *e = getenv("LDPC_HIP_CN_VARIANT")) cn_variant = atoi(e);
     const int cn_requested = cn_variant;
@@ -278,7 +279,9 @@ struct BinaryEngine : Engine {
     // (float sum-product with row weights <= 16, e.g. the DVB-S2 codes: register-resident kernel)
     if (cn_variant == 0)
       cn_variant = ((ALG == ALG_MS || ALG == ALG_MSQ) && rmax <= 64) ? 5 : (ALG == ALG_TAB || (ALG == ALG_MS && sizeof(T) == 8)) ? 4 :
-                   (ALG == ALG_SPA && rmax <= 16) ? 3 : 2;
+                   (ALG == ALG_SPA && rmax <= 16) ? 3 : (ALG == ALG_SPA && sizeof(T) == 8 && rmax <= 64 && LDPC_SPA_F64_PRODUCT) ? 7 : 2;
+    // 7: binary64 sum-product, row weights 17 ... 64, chunked tanh-domain kernel (cn_spa64_chunk_kernel)
+    if (cn_variant == 7 && !(ALG == ALG_SPA && sizeof(T) == 8 && rmax > 16 && rmax <= 64 && LDPC_SPA_F64_PRODUCT)) cn_variant = (ALG == ALG_SPA && rmax <= 16) ? 3 : 2;
     const size_t lds_need = (size_t)rmax * 1024;
     if ((cn_variant == 1 || cn_variant == 4) && lds_need > 160 * 1024) cn_variant = 2;
     if (cn_variant == 3 && ALG == ALG_SPA && rmax > 16) cn_variant = 2;
@@ -429,6 +432,13 @@ struct BinaryEngine : Engine {
                              hard.as<uint8_t>(), sy, fail.as<uint32_t>(), tab);
       }
       LAUNCHCHK("cn_reg_kernel");
+      return LDPC_OK;
+    }
+    if (cn_variant == 7) {
+      if constexpr (ALG == ALG_SPA && sizeof(T) == 8)
+        hipLaunchKernelGGL((cn_spa64_chunk_kernel<8>), grid, block, 0, st, g, nslab, msg.as<vec>(), hard.as<uint8_t>(), sy,
+                           fail.as<uint32_t>());
+      LAUNCHCHK("cn_spa64_chunk_kernel");
       return LDPC_OK;
     }
     if (cn_variant == 5) {

@@ -422,6 +422,47 @@ def test_spa_register_kernel_equals_two_sweep_kernels(hip, oracle, tmp_path, nam
                 assert np.array_equal(o[k], outs[0][k]), k
 
 
+@pytest.mark.parametrize("name,F,sigma,it", [("peg_16000_3_0.9.txt", 24, 0.43, 14), ("4095.737.3.txt", 60, 0.52, 14),
+                                             ("32000.2240.3.105.txt", 10, 0.39, 12)])
+def test_spa_f64_chunked_kernel_for_heavy_checks(hip, oracle, name, F, sigma, it):
+    """Row weights 17 ... 64 (PEG-16000: 30, 4095.737: 17, 32000.2240: 43): the chunked tanh-domain check kernel
+    (cn_variant 7, the default there since round 3; binary_kernels.hip.h cn_spa64_chunk_kernel) against the
+    two-sweep reload kernel, which keeps the reference's sum of logarithms, and against the oracle.  Same
+    mathematics, different roundings: verdicts, iteration counts and syndromes equal on every frame the oracle
+    decodes without NaN, the words of its converged frames equal, posteriors to 1e-9 relative (median)."""
+    oc = oracle.load(code_path(name))
+    xa, sa, la = make_frames(oracle, oc, F - F // 3, 0.01, 77, "awgn", sigma=sigma)
+    xb, sb, lb = make_frames(oracle, oc, F // 3, 0.01, 78, "awgn", sigma=sigma * 1.22)     # frames that do not converge
+    s, llr = np.concatenate([sa, sb]), np.concatenate([la, lb])
+    llr[1] *= 30.0           # saturated tanh: products of exactly 1, the reference's +inf / NaN path
+    llr[2, ::9] = 0.0        # tanh(0) = 0: the reference's log(0)
+    su = s.astype(np.uint8)
+    ref = run_oracle(oracle.dec_spa, oc, llr, s, it)
+    code = hip.Code.from_alist(code_path(name))
+    want = ("bits", "iters", "synd", "status", "llr")
+    outs = {}
+    for variant in (0, 7, 2):
+        dec = hip.Decoder(code, hip.ALG.SPA_F64, max_frames=64, want_llr=True, cn_variant=variant)
+        outs[variant] = dec.decode(llr, su, it, want=want)
+        dec.close()
+    for k in want:                                         # 7 IS the default
+        assert np.array_equal(outs[0][k], outs[7][k], equal_nan=True), k
+    nan = np.isnan(ref[4]).any(axis=1)
+    print(f"{name}: {nan.sum()} of {F} frames hit the reference's NaN; verdicts {np.bincount(ref[3], minlength=2)}")
+    assert (~nan).sum() >= 0.5 * F and (ref[3] != 0).any() and (ref[3] == 0).any()
+    for other, tag in ((outs[2], "two-sweep kernel"), ({"status": ref[3], "iters": ref[1], "synd": ref[2], "bits": ref[0],
+                                                       "llr": ref[4]}, "oracle")):
+        ok = ~nan
+        assert np.array_equal(outs[7]["status"][ok], other["status"][ok]), tag
+        assert np.array_equal(outs[7]["iters"][ok], other["iters"][ok]), tag
+        assert np.array_equal(outs[7]["synd"][ok], other["synd"][ok]), tag
+        conv = ok & (ref[3] == 0)
+        assert np.array_equal(outs[7]["bits"][conv], other["bits"][conv]), tag
+        a, b = outs[7]["llr"][ok].astype(np.float64), np.asarray(other["llr"])[ok].astype(np.float32).astype(np.float64)
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.median(np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1.0)) < 1e-9, tag
+
+
 @pytest.mark.parametrize("name,F,sigma,it", [("dvb_H_0.5.txt", 5, 0.84, 50), ("Frolov_1024_0.5.txt", 60, 0.62, 30),
                                              ("204.33.484.txt", 200, 0.55, 30)])
 def test_spa_f32_follows_the_double_reference_past_binary32_saturation(hip, oracle, tmp_path, name, F, sigma, it):
