@@ -365,7 +365,10 @@ int  ldpc_gfmc_last_pass(ldpc_gfmc *mc, int nframes, uint8_t *x, uint8_t *xhat, 
  * used (set LDPC_HIP_DEVICE to override).  The cached decoders are shared, so
  * these entry points are serialised per process by one lock (the reference's
  * functions work in file-scope globals and are not re-entrant either); for
- * concurrent decoding use one ldpc_decoder per host thread.                  */
+ * concurrent decoding use one ldpc_decoder per host thread.
+ * LDPC_HIP_DEVICES = "all" or a list ("0,1,2,3"): the Monte-Carlo harnesses (*_cw_noise_gen,
+ * test_code_B) split the trials of ONE call over the listed GPUs -- a worker thread, decoder and
+ * generator per entry, counters added up; the result does not depend on the list.            */
 
 /* test_code_min_sum_B(), test_code_min_sum_B.c:331-359 (single frame, caller's x,s,y,q0) */
 int test_code_min_sum_B(const char *code_filename, int iteration, int *x, int *s, int *y,

@@ -14,7 +14,9 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/ldpc_hip.h"
 #include "engine.h"
@@ -76,6 +78,9 @@ struct Cached {
   ldpc_decoder *dec;
   ldpc_mc *mc;        // device Monte-Carlo context (binary codes), made on first use
   uint64_t used;      // tick of the last call that asked for it
+  int slot = 0;       // position in the device list (LDPC_HIP_DEVICES): one decoder per entry of the list
+  int device = 0;
+  int busy = 0;       // held by a worker thread of a multi-device run: not to be evicted
 };
 std::vector<Cached> g_cache;
 uint64_t g_cache_tick = 0;
@@ -83,15 +88,17 @@ uint64_t g_cache_tick = 0;
 // engine); a sweep over many codes and algorithms must not grow without bound.  At most
 // LDPC_HIP_CACHE_MAX (default 6) decoders stay; the least recently used goes first.  The entry
 // points are serialised (SERIALISED), so nothing but the caller's own decoder is in use.
+std::vector<int> device_list();
 size_t cache_max() {
   if (const char *e = getenv("LDPC_HIP_CACHE_MAX")) { const int v = atoi(e); if (v > 0) return (size_t)v; }
-  return 6;
+  return std::max<size_t>(6, 2 * device_list().size());     // (a multi-device run keeps one decoder per entry of its list)
 }
 void evict_lru_locked() {
   while (g_cache.size() >= cache_max()) {
-    size_t old = 0;
-    for (size_t i = 1; i < g_cache.size(); i++)
-      if (g_cache[i].used < g_cache[old].used) old = i;
+    size_t old = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); i++)
+      if (!g_cache[i].busy && (old == g_cache.size() || g_cache[i].used < g_cache[old].used)) old = i;
+    if (old == g_cache.size()) return;     // (everything is in use by a multi-device run)
     if (g_cache[old].mc) ldpc_mc_free(g_cache[old].mc);
     ldpc_decoder_free(g_cache[old].dec);
     ldpc_code_free(g_cache[old].code);
@@ -118,23 +125,54 @@ int cache_device() {
   return 0;
 }
 
+// The GPUs a Monte-Carlo harness call spreads its trials over: LDPC_HIP_DEVICES = "all" or a comma-separated list
+// (one worker thread, decoder and generator per entry; an entry may repeat); unset: the one device of
+// LDPC_HIP_DEVICE.  The reference runs one dec() at a time on one core; its MATLAB drivers get their parallelism
+// from parfor workers (test_mex_B_float.m:24-30) -- this is the same idea inside one call, for callers that have
+// one process and eight GPUs.  Frames are keyed by their global index, so the counters do not depend on the list.
+std::vector<int> device_list() {
+  std::vector<int> v;
+  if (const char *e = getenv("LDPC_HIP_DEVICES")) {
+    if (!strcmp(e, "all")) {
+      int n = 0;
+      if (hipGetDeviceCount(&n) == hipSuccess)
+        for (int i = 0; i < n; i++) v.push_back(i);
+    } else {
+      for (const char *p = e; *p;) {
+        char *end;
+        const long d = strtol(p, &end, 10);
+        if (end == p) break;
+        v.push_back((int)d);
+        p = *end == ',' ? end + 1 : end;
+      }
+    }
+  }
+  if (v.empty()) v.push_back(cache_device());
+  return v;
+}
+
 // frames = 0: a Monte-Carlo pass (mc_batch); > 0: a decoder for that many frames per call (the
 // single-frame harnesses ask for 64, so that one frame does not reserve a Monte-Carlo pass's workspace)
-int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec, ldpc_mc **mc = nullptr, int frames = 0) {
+// slot / device: the entry of the device list (hold = true: the caller is a worker thread of a multi-device run and
+// gives the entry back with release_decoder())
+int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec, ldpc_mc **mc = nullptr, int frames = 0,
+                int slot = 0, int device = -1, bool hold = false) {
   if (!file) return LDPC_ERR_ARG;
+  if (device < 0) device = cache_device();
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto &c : g_cache)
-    if (c.alg == alg && c.frames == frames && c.file == file) {
+    if (c.alg == alg && c.frames == frames && c.slot == slot && c.device == device && c.file == file) {
       c.used = ++g_cache_tick;
       *code = c.code;
       *dec = c.dec;
       if (mc) {
         if (!c.mc) {
-          int rc = ldpc_mc_create(c.code, c.dec, cache_device(), &c.mc);
+          int rc = ldpc_mc_create(c.code, c.dec, device, &c.mc);
           if (rc) return rc;
         }
         *mc = c.mc;
       }
+      if (hold) c.busy++;
       return LDPC_OK;
     }
   evict_lru_locked();
@@ -144,7 +182,7 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
   ldpc_opts o;
   memset(&o, 0, sizeof o);
   o.alg = alg;
-  o.device = cache_device();
+  o.device = device;
   o.max_frames = frames > 0 ? frames : mc_batch(c);
   o.early_exit = 1;
   ldpc_decoder *d = nullptr;
@@ -163,10 +201,18 @@ int get_decoder(const char *file, int alg, ldpc_code **code, ldpc_decoder **dec,
     }
     *mc = m;
   }
-  g_cache.push_back({file, alg, frames, c, d, m, ++g_cache_tick});
+  Cached entry{file, alg, frames, c, d, m, ++g_cache_tick};
+  entry.slot = slot; entry.device = device; entry.busy = hold ? 1 : 0;
+  g_cache.push_back(entry);
   *code = c;
   *dec = d;
   return LDPC_OK;
+}
+
+void release_decoder(const ldpc_decoder *dec) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &c : g_cache)
+    if (c.dec == dec && c.busy > 0) c.busy--;
 }
 
 // CSR copy of a code for the host-side enc()
@@ -203,11 +249,6 @@ int monte_carlo_bsc(const char *file, int alg, int iteration, int trials, double
   if (!errors) return LDPC_ERR_ARG;
   errors[0] = errors[1] = 0;
   if (trials < 0 || iteration < 0) return LDPC_ERR_ARG;
-  ldpc_code *code;
-  ldpc_decoder *dec;
-  ldpc_mc *mc = nullptr;
-  int rc = get_decoder(file, alg, &code, &dec, &mc);
-  if (rc) return rc;
   Rng r = take_rng();
   ldpc_mc_opts o;
   memset(&o, 0, sizeof o);
@@ -217,11 +258,43 @@ int monte_carlo_bsc(const char *file, int alg, int iteration, int trials, double
   o.max_iter = iteration;
   o.param = p_bsc;
   o.seed = r.next();
-  uint64_t counters[8];
-  rc = ldpc_mc_run(mc, &o, trials, counters);
-  if (rc) return rc;
-  errors[0] = (double)counters[1];
-  errors[1] = (double)counters[2];
+  const std::vector<int> devs = device_list();
+  const int nd = (int)std::min<size_t>(devs.size(), (size_t)std::max(1, trials));
+  // trials in contiguous shares, one worker thread per entry of the device list (one entry: this thread)
+  std::vector<uint64_t> counters((size_t)nd * 8, 0);
+  std::vector<int> rcs((size_t)nd, LDPC_OK);
+  std::vector<std::string> msgs((size_t)nd);
+  auto work = [&](int i) {
+    const int64_t lo = (int64_t)trials * i / nd, hi = (int64_t)trials * (i + 1) / nd;
+    ldpc_code *code;
+    ldpc_decoder *dec;
+    ldpc_mc *mc = nullptr;
+    int rc = get_decoder(file, alg, &code, &dec, &mc, 0, i, devs[(size_t)i], nd > 1);
+    if (rc == LDPC_OK) {
+      ldpc_mc_opts oi = o;
+      oi.first_frame = (uint64_t)lo;
+      rc = ldpc_mc_run(mc, &oi, hi - lo, &counters[(size_t)i * 8]);
+      if (nd > 1) release_decoder(dec);
+    }
+    rcs[(size_t)i] = rc;
+    if (rc) msgs[(size_t)i] = ldpc_last_error();     // (thread-local in the library: carried back to the caller's thread)
+  };
+  if (nd == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < nd; i++) th.emplace_back(work, i);
+    for (auto &t : th) t.join();
+  }
+  for (int i = 0; i < nd; i++)
+    if (rcs[(size_t)i]) {
+      ldpc_set_error(msgs[(size_t)i]);
+      return rcs[(size_t)i];
+    }
+  for (int i = 0; i < nd; i++) {
+    errors[0] += (double)counters[(size_t)i * 8 + 1];
+    errors[1] += (double)counters[(size_t)i * 8 + 2];
+  }
   return LDPC_OK;
 }
 

@@ -154,6 +154,40 @@ def test_monte_carlo_entry_points(hip):
     assert a.tolist() == b.tolist() and 0 < a[0] < 400
 
 
+def test_monte_carlo_entry_points_over_a_device_list(hip, monkeypatch):
+    """LDPC_HIP_DEVICES spreads the trials of a harness call over worker threads, one decoder per entry of the
+    list.  Frames are keyed by their global index, so the counters must not depend on the list: the same call
+    on one device, on a list that names this box's one GPU three times, and on "all"."""
+    L = hip.load_library()
+    path = code_path("1057.244.3.txt").encode()
+    res = {}
+    for devs in (None, "0,0,0", "all", "0,0"):
+        if devs is None:
+            monkeypatch.delenv("LDPC_HIP_DEVICES", raising=False)
+        else:
+            monkeypatch.setenv("LDPC_HIP_DEVICES", devs)
+        out = []
+        for fn, p in ((L.test_code_min_sum_B_fixed_cw_noise_gen, 0.0075), (L.test_code_B_float_cw_noise_gen, 0.012)):
+            L.ldpc_set_seed(2026)
+            err = np.zeros(2)
+            assert fn(path, 12, 1001, p, _dp(err)) == 0, L.ldpc_last_error()
+            out.append(err.tolist())
+        L.ldpc_set_seed(5)
+        err = np.zeros(2)
+        assert L.test_code_B(12, 777, 0.011, path, _dp(err)) == 0, L.ldpc_last_error()
+        out.append(err.tolist())
+        res[devs] = out
+    print(res)
+    assert all(0 < e[0] < 1001 for e in res[None]), "the points must sit in the waterfall"
+    for devs in ("0,0,0", "all", "0,0"):
+        assert res[devs] == res[None], devs
+    # an entry that is no device: the error comes back from the worker thread
+    monkeypatch.setenv("LDPC_HIP_DEVICES", "0,99")
+    err = np.zeros(2)
+    assert L.test_code_min_sum_B_cw_noise_gen(path, 5, 100, 0.01, _dp(err)) != 0
+    assert L.ldpc_last_error()
+
+
 def test_python_run_api(hip, oracle):
     """ldpc_decode.run(H, LLR, max_iter): the call shape of LDPC_decode.py:348-374."""
     from ldpc_amd import ldpc_decode
