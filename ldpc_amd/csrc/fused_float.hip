@@ -1276,7 +1276,8 @@ __global__ __launch_bounds__(LB, MINW) void fused_ms_wide_kernel(FfArgs a) {
   X(2, 16, 16, 3, 1024, 4) /* peg_16000_3_0.9 */ \
   X(2, 9, 10, 3, 512, 4)   /* 4095.737.3 */ \
   X(1, 7, 6, 3, 256, 4)    /* 1057.244.3 */ \
-  X(1, 3, 2, 3, 128, 4)    /* 204.33.484 */
+  X(1, 3, 2, 3, 128, 4)    /* 204.33.484 */ \
+  X(1, 5, 2, 7, 1024, 4)   /* Frolov_1024_0.5 (the Verilog trace's code): irregular, column weights to 7 */
 
 // the wide-row binary32 kernel (33 ... 48 slots per check)
 #define FF_WIDE_SHAPES(X) \
