@@ -586,9 +586,10 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    ms_k, cnt_k = (np.zeros(4), np.zeros(4, np.int32))
+    ms_k, cnt_k, fl_k = (np.zeros(4), np.zeros(4, np.int32), np.zeros(4, np.int64))
     if not args.no_profile:
         ms_k, cnt_k = dec.profile_read()
+        fl_k = dec.profile_frames()
         dec.profile(False)
     if args.pmc_child:
         return
@@ -683,8 +684,12 @@ def main():
         total_frames = F * args.steps * world
         value = K_info * total_frames / elapsed / 1e9
         names = ["vn_kernel", "cn_kernel", "fused_decode_kernel", "other"]
-        per_launch_bytes = [(2 * E * b_msg + n * b_msg) * F, 2 * E * b_msg * F,
-                            args.iters * (4 * E * b_msg + n * b_msg) * F, 0]
+        # frames per launch of each kernel class: F for the frame-resident kernels; the two-pass engine cuts a large
+        # call into spans of frames (BinaryEngine::frames_per_span), so its launches are priced by the frames each
+        # worked on (ldpc_decoder_profile_frames: summed over the launches)
+        fpl = [float(fl_k[i]) / max(1, int(cnt_k[i])) if fl_k[i] else float(F) for i in range(4)]
+        per_launch_bytes = [int((2 * E * b_msg + n * b_msg) * fpl[0]), int(2 * E * b_msg * fpl[1]),
+                            int(args.iters * (4 * E * b_msg + n * b_msg) * fpl[2]), 0]
         roofline = None
         if cnt_k.sum() > 0:
             k = int(np.argmax(ms_k))
@@ -726,7 +731,9 @@ def main():
                 roofline = {"bound": "hbm", "achieved": round(ach_hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach_hbm / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes_per_launch": per_launch_bytes[k],
-                            "figure": "algorithmic bytes per launch (SURVEY 8d) / launch time"}
+                            "frames_per_launch": round(fpl[k], 1),
+                            "figure": "algorithmic bytes per launch (SURVEY 8d: that pass's bytes per frame x the mean "
+                                      "frames per launch) / mean launch time"}
             roofline.update(common)
         whole = args.iters * (4 * E * b_msg + n * b_msg) * total_frames / elapsed / 1e9 / world
         fmt = {"q88": "Q8.8 fixed-point", "f32": "binary32", "f64": "binary64"}[args.alg]

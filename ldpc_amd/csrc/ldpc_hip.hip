@@ -479,9 +479,47 @@ struct BinaryEngine : Engine {
   // iterations remain); the open frames are decoded again, from their channel values, as a dense
   // batch of their own.  dec() is deterministic, so a frame's bits, iteration count, syndrome and
   // verdict are the ones one stage gives (LDPC_HIP_TWO_STAGE=0 turns the second stage off).
+  // Frames per pass over the message store.  The min-sum passes are bound by memory traffic, and a message store that
+  // stays in the 256 MB Infinity Cache moves 6.0 - 6.4 TB/s in their access shape against 4.9 TB/s from HBM
+  // (tools/hbm_ceiling with 64 - 192 MiB buffers against 1 - 4 GiB): a large call is cut into
+  // spans of about 240 MB of messages, each decoded to the end before the next starts.  PEG-16000: Q8.8 14.8 -> 17.5
+  // Gbit/s, binary32 7.7 -> 9.6, binary64 3.9 -> 4.9.  The sum-product passes are bound by arithmetic and gain
+  // nothing (tools/probes/batch_sweep.sh), so they are not cut.  LDPC_HIP_PASS_MB overrides (0: never cut).
+  int frames_per_span(int nframes) const {
+    double mb = (ALG == ALG_MS || ALG == ALG_MSQ) ? 240.0 : 0.0;
+    if (const char *e = getenv("LDPC_HIP_PASS_MB")) mb = atof(e);
+    if (mb <= 0.0) return nframes;
+    const double per_frame = (double)E * sizeof(T);
+    long per0 = (long)(mb * 1e6 / per_frame / SF + 0.5) * SF;   // (whole slabs: 64 lanes x V frames each)
+    if (per0 < SF) per0 = SF;
+    // (spans of exactly that size and a shorter last one: evening them out rounds up to whole slabs, and the measured
+    // optimum is narrow -- PEG-16000 Q8.8: 2 560 frames per span 17.5 Gbit/s, 3 072 frames 16.5)
+    return 2 * (long)nframes >= 3 * per0 ? (int)per0 : nframes;
+  }
+
   int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
              int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
              hipStream_t st) override {
+    const int per = frames_per_span(nframes);
+    if (per >= nframes || dt < 0 || dt > 3 || !llr || nframes > nslab_max * SF)   // (bad arguments: decode_span says so)
+      return decode_span(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+    static const size_t elt[4] = {8, 4, 2, 4};
+    int most = 0;
+    for (int f0 = 0; f0 < nframes; f0 += per) {
+      const int cnt = std::min(per, nframes - f0);
+      const int rc = decode_span(cnt, (const char *)llr + (size_t)f0 * n * elt[dt], dt, sy_in ? sy_in + (size_t)f0 * m : nullptr, max_iter,
+                                 bits ? bits + (size_t)f0 * n : nullptr, iters_out ? iters_out + f0 : nullptr,
+                                 sout_out ? sout_out + (size_t)f0 * m : nullptr, status ? status + f0 : nullptr,
+                                 llr_out ? llr_out + (size_t)f0 * n : nullptr, st);
+      if (rc) return rc;
+      most = std::max(most, last_iterations);
+    }
+    last_iterations = most;
+    return LDPC_OK;
+  }
+
+  int decode_span(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+                  int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out, hipStream_t st) {
     const char *ts_env = getenv("LDPC_HIP_TWO_STAGE");
     const bool two_stage_env = !ts_env || atoi(ts_env) != 0;
     const bool two = two_stage_env && !one_stage_only && opts.early_exit != 0 && nframes >= 8 * SF && max_iter >= 16 &&

@@ -327,6 +327,49 @@ def test_q88_on_shapes_the_fused_decoder_must_turn_down(hip, oracle, tmp_path, s
         check_exact(dec.decode(raw, s.astype(np.uint8), it), ref, f"{shape} LDPC_HIP_FUSED={fused}")
 
 
+@pytest.mark.parametrize("prec", ["q88", "f32", "f64"])
+def test_two_pass_minsum_cut_into_spans(hip, oracle, prec):
+    """A large call to the two-pass min-sum engine is decoded in spans of frames whose message store fits the Infinity
+    Cache (BinaryEngine::frames_per_span).  With the span squeezed to the smallest the engine allows
+    (LDPC_HIP_PASS_MB), 1 000 frames -- a ragged last span -- with non-zero syndromes must come out as the oracle
+    has them and as the uncut call does: bits, iteration counts, syndromes, verdicts, posteriors."""
+    import os
+    name, F, it = "1057.244.3.txt", 1000, 15
+    oc = oracle.load(code_path(name))
+    x, s, llr = make_frames(oracle, oc, F, 0.55, 31, "awgn", sigma=0.55)
+    code = hip.Code.from_alist(code_path(name))
+    if prec == "q88":
+        q, inp = to_q88(llr)
+        ref = run_oracle(lambda c, l, sy, k: oracle.dec_minsum_fixed(c, l, sy, k, None, oc.m + 1), oc, q, s, it)
+        alg = hip.ALG.MINSUM_Q88
+    elif prec == "f32":
+        inp = llr.astype(np.float32)
+        ref = run_oracle(oracle.dec_minsum_f32, oc, inp, s, it)
+        alg = hip.ALG.MINSUM_F32
+    else:
+        inp = llr
+        ref = run_oracle(oracle.dec_minsum, oc, inp, s, it)
+        alg = hip.ALG.MINSUM_F64
+    assert 0 < (ref[3] != 0).sum() < F                      # frames that converge and frames that do not
+    os.environ["LDPC_HIP_FUSED"] = "0"                      # the two-pass engine
+    try:
+        decs = [hip.Decoder(code, alg, max_frames=1024, early_exit=e, want_llr=True) for e in (True, False)]
+    finally:
+        del os.environ["LDPC_HIP_FUSED"]
+    want = ("bits", "iters", "synd", "status", "llr")
+    for dec in decs:
+        outs = {}
+        for mb in ("0.3", "0"):                             # spans of one or two slabs; never cut
+            os.environ["LDPC_HIP_PASS_MB"] = mb
+            try:
+                outs[mb] = dec.decode(inp, s.astype(np.uint8), it, want=want)
+            finally:
+                del os.environ["LDPC_HIP_PASS_MB"]
+            check_exact(outs[mb], ref, f"{prec} spans of {mb} MB")
+        for k in want:
+            assert np.array_equal(outs["0.3"][k], outs["0"][k]), f"{prec}: {k} of the cut call differs from the uncut call's"
+
+
 @pytest.mark.parametrize("n,m,dv,it", [(96, 48, 3, 10), (520, 130, 3, 12), (2000, 200, 3, 8), (3000, 150, 3, 8),
                                        (1200, 1150, 3, 15), (4000, 1000, 4, 8), (777, 259, 5, 10), (6000, 300, 2, 6),
                                        (2044, 1022, 6, 10), (6000, 4000, 3, 10)])
