@@ -338,8 +338,8 @@ CONFIG_LEGS = [
     dict(id="configs[2]/MINSUM_F32", code="dvb_H_0.5.txt", alg="MINSUM_F32", dt="F32", channel="AWGN", ebn0=2.4, iters=50,
          frames=4096, batch=4096, fused=True, kernel="stair_f32", b=4,
          what="DVB-S2 rate 1/2 binary32 min-sum (staircase frame-resident kernel), Eb/N0 = 2.4 dB, <= 50 iterations, early exit",
-         note="bounded by the HBM traffic of its per-workgroup record rows (14.3 MB per frame at 10 iterations, "
-              "profiles/r03_stair_f32_counters.txt), not by vector issue"),
+         note="the check pass is bound by vector issue, the rebuild of the sums by its 127 barrier steps; its per-workgroup record rows move 14.3 MB per frame at 10 iterations ("
+              "profiles/r03_stair_f32_counters.txt)"),
     dict(id="configs[4]", code="q4.sp.9000.6000.4500.1", alg="GF2P_WHT", dt="I32", channel=None, iters=10, frames=2048,
          batch=2048, fused=False, b=4,
          what="GF(4) q4.sp.9000.6000.4500.1 Walsh-Hadamard check nodes, 10 iterations executed, random priors resident"),

@@ -16,6 +16,10 @@
 //     messages are in the records of checks j and j + 1, which the thread of either check reads (its own
 //     record and both neighbours': the same cache lines); posterior = (q0 + c_j) + c_{j+1}, the column's
 //     order.  Their channel values sit in a per-workgroup global row, written once per frame.
+//     (Tried and taken out: one record set rewritten in place by its own thread, the neighbours' messages
+//     by wavefront shifts and a small LDS array across wavefront borders -- 512 instead of 896 KB per
+//     workgroup, so all rows stay in the Infinity Cache -- check pass 4.37 -> 4.83 ms per 2 048 frames,
+//     rebuild unchanged: the check pass is bound by vector issue, not by where its rows come from.)
 //   * the other variables (the information bits) have binary32 sums in LDS (130 KB), q0 of the thread's
 //     share in registers.  After the check pass the sums are REBUILT in the reference's order: sum = q0,
 //     then the rounds in turn, every check adding its new message to the sums of its variables (a plain
