@@ -153,10 +153,11 @@ constexpr int EV_RING = 4;
 // ---- second stage of a two-stage decode (BinaryEngine::decode): the frames that have not met their
 // syndrome when the first stage stops are listed, their inputs gathered into a dense batch, and
 // their results written back over the first stage's
-__global__ void list_open_frames_kernel(int nframes, int V, const uint8_t *done, int *count, int *idx) {
+// (first: number of the span's first frame in the caller's batch)
+__global__ void list_open_frames_kernel(int nframes, int V, const uint8_t *done, int *count, int *idx, int first) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nframes) return;
-  if (!((done[f / V] >> (f % V)) & 1)) idx[atomicAdd(count, 1)] = f;
+  if (!((done[f / V] >> (f % V)) & 1)) idx[atomicAdd(count, 1)] = first + f;
 }
 // rows of `row` bytes: dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter); one workgroup per row
 template <typename U, bool SCATTER>
@@ -483,59 +484,73 @@ struct BinaryEngine : Engine {
   // stays in the 256 MB Infinity Cache moves 6.0 - 6.4 TB/s in their access shape against 4.9 TB/s from HBM
   // (tools/hbm_ceiling with 64 - 192 MiB buffers against 1 - 4 GiB): a large call is cut into
   // spans of about 240 MB of messages, each decoded to the end before the next starts.  PEG-16000: Q8.8 14.8 -> 17.5
-  // Gbit/s, binary32 7.7 -> 9.6, binary64 3.9 -> 4.9.  The sum-product passes are bound by arithmetic and gain
-  // nothing (tools/probes/batch_sweep.sh), so they are not cut.  LDPC_HIP_PASS_MB overrides (0: never cut).
+  // Gbit/s, binary32 7.7 -> 9.6, binary64 3.9 -> 4.9.  The float sum-product passes are bound by arithmetic and gain
+  // less (+2 ... +15 %); the table sum-product's persistent check kernel loses on small spans and is not cut.
+  // LDPC_HIP_PASS_MB overrides (0: never cut).
   int frames_per_span(int nframes) const {
-    double mb = (ALG == ALG_MS || ALG == ALG_MSQ) ? 240.0 : 0.0;
+    double mb = ALG == ALG_TAB ? 0.0 : 240.0;
     if (const char *e = getenv("LDPC_HIP_PASS_MB")) mb = atof(e);
     if (mb <= 0.0) return nframes;
     const double per_frame = (double)E * sizeof(T);
-    long per0 = (long)(mb * 1e6 / per_frame / SF + 0.5) * SF;   // (whole slabs: 64 lanes x V frames each)
-    if (per0 < SF) per0 = SF;
+    // whole slabs (64 lanes x V frames each), at least two: DVB-S2 0.5, whose slab alone is 232 MB, gains nothing from
+    // one-slab spans and 13 - 17 % from two (tools/probes/span_sweep.sh, profiles/r03_twopass_spans.txt)
+    long per0 = std::max(2L, (long)(mb * 1e6 / per_frame / SF + 0.5)) * SF;
+    // the sum-product check passes are bound by arithmetic: a span must still fill the GPU several times over
+    // (32000.2240, 2 240 checks: 256-frame spans cost SPA_F64 8 %; PEG-16000, 1 600 checks: 640-frame spans gain 7 %),
+    // so at least 10^6 check-frames per launch
+    if (ALG != ALG_MS && ALG != ALG_MSQ)
+      per0 = std::max(per0, ((1000000L + m - 1) / m + SF - 1) / SF * SF);
+    if (const char *e = getenv("LDPC_HIP_PASS_SLABS")) per0 = std::max(1L, (long)atoi(e)) * SF;   // (tuning)
     // (spans of exactly that size and a shorter last one: evening them out rounds up to whole slabs, and the measured
     // optimum is narrow -- PEG-16000 Q8.8: 2 560 frames per span 17.5 Gbit/s, 3 072 frames 16.5)
     return 2 * (long)nframes >= 3 * per0 ? (int)per0 : nframes;
   }
 
-  int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
-             int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
-             hipStream_t st) override {
-    const int per = frames_per_span(nframes);
-    if (per >= nframes || dt < 0 || dt > 3 || !llr || nframes > nslab_max * SF)   // (bad arguments: decode_span says so)
-      return decode_span(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st);
+  // One span after the other through decode_once(); f0 = first frame of the span in the caller's arrays.
+  // stage1: stop a span's iterations once at most 1/16 of its frames are still open and list those (numbered within the
+  // caller's batch) at d_idx / d_count.
+  int decode_spans(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits, int32_t *iters_out,
+                   uint8_t *sout_out, int32_t *status, float *llr_out, hipStream_t st, bool stage1, int *d_count, int *d_idx) {
     static const size_t elt[4] = {8, 4, 2, 4};
+    int per = frames_per_span(nframes);
+    if (dt < 0 || dt > 3 || !llr || nframes > nslab_max * SF) per = nframes;   // (bad arguments: decode_once says so)
     int most = 0;
     for (int f0 = 0; f0 < nframes; f0 += per) {
       const int cnt = std::min(per, nframes - f0);
-      const int rc = decode_span(cnt, (const char *)llr + (size_t)f0 * n * elt[dt], dt, sy_in ? sy_in + (size_t)f0 * m : nullptr, max_iter,
-                                 bits ? bits + (size_t)f0 * n : nullptr, iters_out ? iters_out + f0 : nullptr,
-                                 sout_out ? sout_out + (size_t)f0 * m : nullptr, status ? status + f0 : nullptr,
-                                 llr_out ? llr_out + (size_t)f0 * n : nullptr, st);
+      bool stopped = false;
+      const int rc = decode_once(cnt, per < nframes ? (const void *)((const char *)llr + (size_t)f0 * n * elt[dt]) : llr, dt,
+                                 sy_in ? sy_in + (size_t)f0 * m : nullptr, max_iter, bits ? bits + (size_t)f0 * n : nullptr,
+                                 iters_out ? iters_out + f0 : nullptr, sout_out ? sout_out + (size_t)f0 * m : nullptr,
+                                 status ? status + f0 : nullptr, llr_out ? llr_out + (size_t)f0 * n : nullptr, st,
+                                 stage1 ? cnt / 16 : 0, stage1 ? &stopped : nullptr);
       if (rc) return rc;
       most = std::max(most, last_iterations);
+      if (stopped) {
+        hipLaunchKernelGGL(list_open_frames_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, cnt, V, done.as<uint8_t>(), d_count,
+                           d_idx, f0);
+        LAUNCHCHK("list_open_frames_kernel");
+      }
     }
     last_iterations = most;
     return LDPC_OK;
   }
 
-  int decode_span(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
-                  int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out, hipStream_t st) {
+  int decode(int nframes, const void *llr, int dt, const uint8_t *sy_in, int max_iter, uint8_t *bits,
+             int32_t *iters_out, uint8_t *sout_out, int32_t *status, float *llr_out,
+             hipStream_t st) override {
+    if (nframes <= 0) return LDPC_OK;
     const char *ts_env = getenv("LDPC_HIP_TWO_STAGE");
     const bool two_stage_env = !ts_env || atoi(ts_env) != 0;
     const bool two = two_stage_env && !one_stage_only && opts.early_exit != 0 && nframes >= 8 * SF && max_iter >= 16 &&
                      dt >= 0 && dt <= 3;
-    if (!two) return decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, 0, nullptr);
-    bool stopped = false;
-    int rc = decode_once(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, nframes / 16, &stopped);
-    if (rc || !stopped) return rc;
-    const int stage1_iterations = last_iterations;
-    // the open frames, in whatever order the lanes report them
+    if (!two) return decode_spans(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, false, nullptr, nullptr);
+    int rc;
     if ((rc = s2_idx.ensure(sizeof(int) * ((size_t)nframes / 16 + 64)))) return rc;
     int *d_count = s2_idx.as<int>(), *d_idx = s2_idx.as<int>() + 32;
     HIPCHK(hipMemsetAsync(d_count, 0, sizeof(int), st));
-    hipLaunchKernelGGL(list_open_frames_kernel, dim3((nframes + 255) / 256), dim3(256), 0, st, nframes, V,
-                       done.as<uint8_t>(), d_count, d_idx);
-    LAUNCHCHK("list_open_frames_kernel");
+    // the first stage, span by span; the frames it leaves open, in whatever order the lanes report them
+    if ((rc = decode_spans(nframes, llr, dt, sy_in, max_iter, bits, iters_out, sout_out, status, llr_out, st, true, d_count, d_idx))) return rc;
+    const int stage1_iterations = last_iterations;
     int count = 0;
     HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -553,9 +568,9 @@ struct BinaryEngine : Engine {
     move_rows<false>(llr, s2_llr.p, d_idx, count, in_row, st);
     if (sy_in) move_rows<false>(sy_in, s2_synd.p, d_idx, count, (size_t)m, st);
     LAUNCHCHK("move_rows_kernel (gather)");
-    rc = decode_once(count, s2_llr.p, dt, sy_in ? s2_synd.as<uint8_t>() : nullptr, max_iter, bits ? s2_bits.as<uint8_t>() : nullptr,
-                     iters_out ? s2_iters.as<int32_t>() : nullptr, sout_out ? s2_sout.as<uint8_t>() : nullptr,
-                     status ? s2_status.as<int32_t>() : nullptr, llr_out ? s2_post.as<float>() : nullptr, st, 0, nullptr);
+    rc = decode_spans(count, s2_llr.p, dt, sy_in ? s2_synd.as<uint8_t>() : nullptr, max_iter, bits ? s2_bits.as<uint8_t>() : nullptr,
+                      iters_out ? s2_iters.as<int32_t>() : nullptr, sout_out ? s2_sout.as<uint8_t>() : nullptr,
+                      status ? s2_status.as<int32_t>() : nullptr, llr_out ? s2_post.as<float>() : nullptr, st, false, nullptr, nullptr);
     if (rc) return rc;
     // d_idx lives in s2_idx, which decode_once does not touch
     if (bits) move_rows<true>(s2_bits.p, bits, d_idx, count, (size_t)n, st);

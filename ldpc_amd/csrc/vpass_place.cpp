@@ -2,6 +2,7 @@
 // floating-point min-sum kernel (fused_float.hip): see ldpc_place_variable_pass().
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "lds_schedule.h"
@@ -11,8 +12,10 @@
 // a ds_read_b128 in the variable pass (thread tid rebuilds words tid + B*i: lane = word mod 64,
 // groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32).  A group is served in one
 // LDS cycle when its 16 records sit in 16 different bank quads (record index mod 16); random
-// ranks give ~3.  Local search over swaps of two variables of one bank: cost = sum over
-// groups and edges of the busiest quad.  Returns the extra LDS cycles left (and before).
+// ranks give ~3.  Local search over swaps of two variables of one bank, one of them in an over-full
+// class of its group: cost = sum over groups and edges of the busiest quad.  Returns the extra LDS
+// cycles left (and before).  PEG-16000, 0.7 s: 6 178 -> 1 800 (ten times the moves: 1 250; a rank's
+// last variables have a 1 in 4 096 chance of fitting three edges at once, so zero is out of reach).
 //
 // wide = true: the wide-row kernel's layout instead -- {min1, min2} pairs of 8 bytes read with ds_read_b64, which is
 // served in two groups of 32 lanes (lanes 0-31, 32-63), one LDS cycle each when the 32 records sit in 32 different
@@ -54,7 +57,7 @@ static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *befor
   long sum = 0;
   for (int t = 0; t < NT; t++) sum += cost(t);
   *before = sum;
-  // simulated annealing on swaps of two variables of one bank.  Energy per (group, edge):
+  // local search on swaps of two variables of one bank.  Energy per (group, edge):
   // 16 * (busiest quad - 1) + number of surplus entries (the second term guides the search
   // where the first is flat).  Counts are kept per (group, edge, quad).
   std::vector<uint8_t> cnt((size_t)NT * CM * QM, 0);
@@ -77,23 +80,51 @@ static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *befor
   uint64_t rng = 0x9E3779B97F4A7C15ull;
   auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 32); };
   const int ranks = W / 32;
-  const long moves = std::min<long>(150L * W, 8000000L);
-  // acceptance of an uphill move of size d: d <= budget, a threshold that falls linearly to 0
+  long moves = std::min<long>(150L * W, 8000000L);
+  int budget0 = 0;   // greedy with sideways moves: every annealing schedule tried ended higher in the same time (PEG-16000: 12 -> 2 642, 4 -> 2 314, 0 -> 1 969 extra cycles)
+  if (const char *e = getenv("LDPC_HIP_VPLACE_MOVES")) moves = (long)(atof(e) * W);      // (tuning: moves per LDS word)
+  if (const char *e = getenv("LDPC_HIP_VPLACE_BUDGET")) budget0 = atoi(e);               // (tuning: first uphill threshold)
+  // acceptance of a move that changes the energy by d: d <= budget, a threshold that falls linearly to 0 (0 from the start by default)
+  // one end of a swap is a variable that sits in an over-full class of some group (moves between two settled
+  // variables only shuffle the plateau)
+  auto in_conflict = [&](int w) {
+    const int v = occ[w];
+    if (v < 0) return false;
+    for (int kk = 0; kk < CM; kk++) {
+      const int q = quad[(size_t)v * CM + kk];
+      if (q >= 0 && cnt[((size_t)tw[w] * CM + kk) * QM + q] > 1) return true;
+    }
+    return false;
+  };
+  int focus = 1;
+  if (const char *e = getenv("LDPC_HIP_VPLACE_FOCUS")) focus = atoi(e);
+  int best_of = 1;
+  if (const char *e = getenv("LDPC_HIP_VPLACE_BESTOF")) best_of = std::max(1, atoi(e));
+  auto swap_counts = [&](int t, int t2, int va, int vb) {   // va leaves t for t2, vb leaves t2 for t
+    add(t, va, -1); add(t2, vb, -1);
+    add(t, vb, +1); add(t2, va, +1);
+  };
   for (long it = 0; it < moves && ranks > 1; it++) {
-    const int w = (int)(rnd() % (uint32_t)W);
-    const int w2 = (w & 31) + 32 * (int)(rnd() % (uint32_t)ranks);
-    const int t = tw[w], t2 = tw[w2];
-    if (t == t2 || (occ[w] < 0 && occ[w2] < 0)) continue;
-    const int e0 = energy_t(t) + energy_t(t2);
-    add(t, occ[w], -1); add(t2, occ[w2], -1);
-    add(t, occ[w2], +1); add(t2, occ[w], +1);
-    const int e1 = energy_t(t) + energy_t(t2);
-    const int budget = (int)((wide ? 24 : 12) * (moves - it) / moves);
-    if (e1 - e0 <= budget - (int)(rnd() % (uint32_t)(budget + 1))) {
+    int w = (int)(rnd() % (uint32_t)W);
+    for (int tries = 0; focus && tries < 16 && !in_conflict(w); tries++) w = (int)(rnd() % (uint32_t)W);
+    const int t = tw[w];
+    // the best of `best_of` partners in the same bank
+    int w2 = -1, d_best = 1 << 30;
+    for (int k = 0; k < best_of; k++) {
+      const int c2 = (w & 31) + 32 * (int)(rnd() % (uint32_t)ranks);
+      const int t2 = tw[c2];
+      if (t == t2 || (occ[w] < 0 && occ[c2] < 0)) continue;
+      const int e0 = energy_t(t) + energy_t(t2);
+      swap_counts(t, t2, occ[w], occ[c2]);
+      const int d = energy_t(t) + energy_t(t2) - e0;
+      swap_counts(t, t2, occ[c2], occ[w]);
+      if (d < d_best) { d_best = d; w2 = c2; }
+    }
+    if (w2 < 0) continue;
+    const int budget = (int)(budget0 * (moves - it) / moves);
+    if (d_best <= budget - (int)(rnd() % (uint32_t)(budget + 1))) {
+      swap_counts(t, tw[w2], occ[w], occ[w2]);
       std::swap(occ[w], occ[w2]);
-    } else {
-      add(t, occ[w2], -1); add(t2, occ[w], -1);
-      add(t, occ[w], +1); add(t2, occ[w2], +1);
     }
   }
   sum = 0;
