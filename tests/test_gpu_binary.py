@@ -611,3 +611,43 @@ def test_spa_f64_on_dvb_s2_across_the_waterfall(hip, oracle, tmp_path):
                 seen_fail += 1
                 assert (out["bits"][f] != ref[0][f]).mean() <= 1e-3, (db, f)
     assert seen_conv >= 2 and seen_fail >= 2, (seen_conv, seen_fail)
+
+
+@pytest.mark.parametrize("alg,F,db,it", [("MINSUM_F64", 1200, 2.0, 30), ("SPA_F32", 2100, 1.05, 40), ("MINSUM_Q88", 2600, 2.0, 12)])
+def test_default_spans_on_dvb_s2_equal_the_uncut_call(hip, alg, F, db, it):
+    """The span sizes the engine picks by itself, at sizes where they matter: DVB-S2 rate 1/2 on the two-pass engine
+    (LDPC_HIP_FUSED=0, LDPC_HIP_CHAIN=0), a slab of 232 MB, spans of two slabs with a ragged tail, frames on either side
+    of the waterfall so that the two-stage early exit (>= 8 slabs, >= 16 iterations) stops spans early and decodes their
+    open frames as one batch.  The uncut call (LDPC_HIP_PASS_MB=0) is the reference point; it is checked against the
+    oracle elsewhere (test_minsum_*, test_spa_*): every output of the cut call must equal it, bit for bit."""
+    import os
+    code = hip.Code.from_alist(code_path("dvb_H_0.5.txt"))
+    n, m = code.n, code.m
+    rng = np.random.default_rng(101)
+    sigma = (1.0 / (2 * 0.5 * 10 ** (db / 10))) ** 0.5
+    # all-zero codeword; one frame in 25 at twice the noise power (they fail: fewer than the 1/16 at which a span's first stage stops), zero syndromes
+    sig = np.where(np.arange(F) % 25 == 3, sigma * 1.41, sigma)[:, None]
+    y = 1.0 + rng.normal(0.0, 1.0, size=(F, n)) * sig
+    llr = 2.0 * y / sig ** 2
+    if alg == "MINSUM_Q88":
+        _, inp = to_q88(llr)
+    else:
+        inp = llr.astype(np.float32) if alg.endswith("F32") else llr
+    os.environ["LDPC_HIP_FUSED"] = "0"
+    os.environ["LDPC_HIP_CHAIN"] = "0"
+    try:
+        dec = hip.Decoder(code, getattr(hip.ALG, alg), max_frames=F, early_exit=True, want_llr=True)
+    finally:
+        del os.environ["LDPC_HIP_FUSED"], os.environ["LDPC_HIP_CHAIN"]
+    want = ("bits", "iters", "synd", "status", "llr")
+    cut = dec.decode(inp, None, it, want=want)
+    os.environ["LDPC_HIP_PASS_MB"] = "0"
+    try:
+        whole = dec.decode(inp, None, it, want=want)
+    finally:
+        del os.environ["LDPC_HIP_PASS_MB"]
+    nfail = int((whole["status"] != 0).sum())
+    print(f"dvb {alg}: {nfail} of {F} frames not converged, iterations {whole['iters'].min()} .. {whole['iters'].max()}")
+    assert 0 < nfail < F
+    for k in want:
+        assert np.array_equal(cut[k], whole[k], equal_nan=(k == "llr")), f"{alg}: {k} of the cut call differs from the uncut call's"
