@@ -3,6 +3,10 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "lds_schedule.h"
@@ -20,7 +24,7 @@
 // wide = true: the wide-row kernel's layout instead -- {min1, min2} pairs of 8 bytes read with ds_read_b64, which is
 // served in two groups of 32 lanes (lanes 0-31, 32-63), one LDS cycle each when the 32 records sit in 32 different
 // bank pairs (record index mod 32).
-static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after, const bool wide) {
+static void place_variable_pass_search(const ldpc_code &c, LdsSchedule &sc, long *before, long *after, const bool wide) {
   const int QM = wide ? 32 : 16;          // bank classes of a record
   std::vector<int> row_of(c.E());
   for (int j = 0; j < c.m; j++)
@@ -58,74 +62,87 @@ static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *befor
   for (int t = 0; t < NT; t++) sum += cost(t);
   *before = sum;
   // local search on swaps of two variables of one bank.  Energy per (group, edge):
-  // 16 * (busiest quad - 1) + number of surplus entries (the second term guides the search
-  // where the first is flat).  Counts are kept per (group, edge, quad).
-  std::vector<uint8_t> cnt((size_t)NT * CM * QM, 0);
-  auto energy_of = [&](int t, int kk) {
-    const uint8_t *q = &cnt[((size_t)t * CM + kk) * QM];
-    int mx = 0, surplus = 0;
-    for (int i = 0; i < QM; i++) { mx = std::max<int>(mx, q[i]); surplus += q[i] > 1 ? q[i] - 1 : 0; }
-    return QM * (mx > 0 ? mx - 1 : 0) + surplus;
+  // QM * (busiest class - 1) + number of surplus entries (the second term guides the search
+  // where the first is flat).  Kept incrementally per (group, edge): the count of every class, how many classes hold
+  // each count, and the largest count -- a variable entering or leaving a group is O(1) per edge.
+  struct Cell { uint8_t cnt[32]; uint8_t hist[40]; uint8_t mx; };   // hist[c] = classes with count c (a group has at most 32 members)
+  // (cells of the two lane sets apart, a bank's words together: the two search threads then share no cache line)
+  const int NTH = (NT + 1) / 2;
+  auto ci = [NTH, wide](int t) { return wide ? t : (t & 1) * NTH + (t >> 1); };
+  std::vector<Cell> cell((size_t)2 * NTH * CM);
+  for (auto &x : cell) { std::fill(x.cnt, x.cnt + 32, 0); std::fill(x.hist, x.hist + 40, 0); x.hist[0] = (uint8_t)QM; x.mx = 0; }
+  auto cell_energy_mx = [&](int mx) { return QM * (mx > 0 ? mx - 1 : 0); };
+  auto bump = [&](Cell &x, int q, int d) {   // count of class q changes by d = +-1; returns the change of the cell's energy
+    const int c = x.cnt[q], c2 = c + d;
+    const int mx0 = x.mx;
+    x.hist[c]--; x.hist[c2]++;
+    x.cnt[q] = (uint8_t)c2;
+    if (c2 > x.mx) x.mx = (uint8_t)c2;
+    else if (d < 0 && c == x.mx && x.hist[c] == 0) x.mx = (uint8_t)c2;
+    return cell_energy_mx(x.mx) - cell_energy_mx(mx0) + ((c2 > 1 ? c2 - 1 : 0) - (c > 1 ? c - 1 : 0));
   };
   auto add = [&](int t, int v, int d) {
-    if (v < 0) return;
+    int de = 0;
+    if (v < 0) return de;
     for (int kk = 0; kk < CM; kk++) {
       const int q = quad[(size_t)v * CM + kk];
-      if (q >= 0) cnt[((size_t)t * CM + kk) * QM + q] = (uint8_t)(cnt[((size_t)t * CM + kk) * QM + q] + d);
+      if (q >= 0) de += bump(cell[(size_t)ci(t) * CM + kk], q, d);
     }
+    return de;
   };
   std::vector<int> tw(W);
   for (int w = 0; w < W; w++) { tw[w] = tuple_of(w); add(tw[w], occ[w], +1); }
-  auto energy_t = [&](int t) { int e = 0; for (int kk = 0; kk < CM; kk++) e += energy_of(t, kk); return e; };
-  uint64_t rng = 0x9E3779B97F4A7C15ull;
-  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 32); };
   const int ranks = W / 32;
-  long moves = std::min<long>(150L * W, 8000000L);
-  int budget0 = 0;   // greedy with sideways moves: every annealing schedule tried ended higher in the same time (PEG-16000: 12 -> 2 642, 4 -> 2 314, 0 -> 1 969 extra cycles)
-  if (const char *e = getenv("LDPC_HIP_VPLACE_MOVES")) moves = (long)(atof(e) * W);      // (tuning: moves per LDS word)
-  if (const char *e = getenv("LDPC_HIP_VPLACE_BUDGET")) budget0 = atoi(e);               // (tuning: first uphill threshold)
-  // acceptance of a move that changes the energy by d: d <= budget, a threshold that falls linearly to 0 (0 from the start by default)
-  // one end of a swap is a variable that sits in an over-full class of some group (moves between two settled
-  // variables only shuffle the plateau)
-  auto in_conflict = [&](int w) {
-    const int v = occ[w];
-    if (v < 0) return false;
-    for (int kk = 0; kk < CM; kk++) {
-      const int q = quad[(size_t)v * CM + kk];
-      if (q >= 0 && cnt[((size_t)tw[w] * CM + kk) * QM + q] > 1) return true;
-    }
-    return false;
-  };
-  int focus = 1;
-  if (const char *e = getenv("LDPC_HIP_VPLACE_FOCUS")) focus = atoi(e);
-  int best_of = 1;
-  if (const char *e = getenv("LDPC_HIP_VPLACE_BESTOF")) best_of = std::max(1, atoi(e));
+  // Plain descent with sideways moves: every annealing schedule tried ended higher in the same time (PEG-16000, 150
+  // moves per word: first uphill threshold 12 -> 2 642 extra cycles, 4 -> 2 314, 0 -> 1 969), and so did the best of K
+  // partners per move.  One end of a swap is a variable that sits in an over-full class of its group (moves between
+  // two settled variables only shuffle the plateau), taken in turn: 1 969 -> 1 800; 600 moves per word: 1 270.
+  // The two lane sets of the ds_read_b128 layout share no bank and no group: two threads, one each.
+  const int parts = wide ? 1 : 2;
+  long moves = std::min<long>((wide ? 300L : 600L) * W, 32000000L) / parts;
+  if (const char *e = getenv("LDPC_HIP_VPLACE_MOVES")) moves = (long)(atof(e) * W) / parts;      // (tuning: moves per LDS word)
   auto swap_counts = [&](int t, int t2, int va, int vb) {   // va leaves t for t2, vb leaves t2 for t
-    add(t, va, -1); add(t2, vb, -1);
-    add(t, vb, +1); add(t2, va, +1);
+    return add(t, va, -1) + add(t2, vb, -1) + add(t, vb, +1) + add(t2, va, +1);
   };
-  for (long it = 0; it < moves && ranks > 1; it++) {
-    int w = (int)(rnd() % (uint32_t)W);
-    for (int tries = 0; focus && tries < 16 && !in_conflict(w); tries++) w = (int)(rnd() % (uint32_t)W);
-    const int t = tw[w];
-    // the best of `best_of` partners in the same bank
-    int w2 = -1, d_best = 1 << 30;
-    for (int k = 0; k < best_of; k++) {
-      const int c2 = (w & 31) + 32 * (int)(rnd() % (uint32_t)ranks);
-      const int t2 = tw[c2];
-      if (t == t2 || (occ[w] < 0 && occ[c2] < 0)) continue;
-      const int e0 = energy_t(t) + energy_t(t2);
-      swap_counts(t, t2, occ[w], occ[c2]);
-      const int d = energy_t(t) + energy_t(t2) - e0;
-      swap_counts(t, t2, occ[c2], occ[w]);
-      if (d < d_best) { d_best = d; w2 = c2; }
+  // a thread works on its own copy of the word -> variable map (it only ever touches the words of its lane set) and
+  // on its own cells; its words are copied back at the end
+  auto search = [&](int part, std::vector<int> &o) {
+    uint64_t rng = 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull * (uint64_t)part;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 32); };
+    auto mine = [&](int w) { return parts == 1 || (tw[w] & 1) == part; };
+    auto in_conflict = [&](int w) {
+      const int v = o[w];
+      if (v < 0) return false;
+      for (int kk = 0; kk < CM; kk++) {
+        const int q = quad[(size_t)v * CM + kk];
+        if (q >= 0 && cell[(size_t)ci(tw[w]) * CM + kk].cnt[q] > 1) return true;
+      }
+      return false;
+    };
+    int w = 0;
+    for (long it = 0; it < moves && ranks > 1; it++) {
+      // (the words in turn, skipping the settled ones: no random probes wasted on them)
+      int tries = 0;
+      for (; tries < W; tries++) {
+        w = w + 1 < W ? w + 1 : 0;
+        if (mine(w) && in_conflict(w)) break;
+      }
+      if (tries == W) break;                                   // nothing left to improve
+      const int w2 = (w & 31) + 32 * (int)(rnd() % (uint32_t)ranks);
+      const int t = tw[w], t2 = tw[w2];
+      if (t == t2 || (o[w] < 0 && o[w2] < 0)) continue;
+      if (swap_counts(t, t2, o[w], o[w2]) <= 0) std::swap(o[w], o[w2]);
+      else swap_counts(t, t2, o[w2], o[w]);
     }
-    if (w2 < 0) continue;
-    const int budget = (int)(budget0 * (moves - it) / moves);
-    if (d_best <= budget - (int)(rnd() % (uint32_t)(budget + 1))) {
-      swap_counts(t, tw[w2], occ[w], occ[w2]);
-      std::swap(occ[w], occ[w2]);
-    }
+  };
+  if (parts == 2) {
+    std::vector<int> o0 = occ, o1 = occ;
+    std::thread other(search, 1, std::ref(o1));
+    search(0, o0);
+    other.join();
+    for (int w = 0; w < W; w++) occ[w] = (tw[w] & 1) ? o1[w] : o0[w];
+  } else {
+    search(0, occ);
   }
   sum = 0;
   for (int t = 0; t < NT; t++) sum += cost(t);
@@ -140,6 +157,41 @@ static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *befor
     if (occ[w] >= 0) sc.pos[occ[w]] = (uint16_t)w;
 }
 
+
+// The search is deterministic and takes a second or two on the long codes: a process that makes several decoders of
+// one code (a sweep over algorithms, the test suite) pays for it once.  Keyed by a hash of the graph and of the
+// schedule the search starts from; a handful of entries, dropped together when full.
+namespace {
+struct PlacedEntry { std::vector<uint16_t> pos, colT; long before, after; };
+std::mutex g_placed_mutex;
+std::map<uint64_t, PlacedEntry> g_placed;
+uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < bytes; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+  return h;
+}
+}  // namespace
+static void place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after, const bool wide) {
+  uint64_t key = 0xCBF29CE484222325ull ^ (wide ? 0x9E37ull : 0);
+  key = fnv(key, c.row_ptr.data(), c.row_ptr.size() * sizeof(int32_t));
+  key = fnv(key, c.col_idx.data(), c.col_idx.size() * sizeof(int32_t));
+  key = fnv(key, sc.pos.data(), sc.pos.size() * sizeof(uint16_t));
+  key = fnv(key, sc.colT.data(), sc.colT.size() * sizeof(uint16_t));
+  if (const char *e = getenv("LDPC_HIP_VPLACE_MOVES")) key = fnv(key, e, strlen(e));
+  {
+    std::lock_guard<std::mutex> lock(g_placed_mutex);
+    auto it = g_placed.find(key);
+    if (it != g_placed.end() && it->second.pos.size() == sc.pos.size() && it->second.colT.size() == sc.colT.size()) {
+      sc.pos = it->second.pos; sc.colT = it->second.colT;
+      *before = it->second.before; *after = it->second.after;
+      return;
+    }
+  }
+  place_variable_pass_search(c, sc, before, after, wide);
+  std::lock_guard<std::mutex> lock(g_placed_mutex);
+  if (g_placed.size() >= 16) g_placed.clear();
+  g_placed[key] = PlacedEntry{sc.pos, sc.colT, *before, *after};
+}
 
 void ldpc_place_variable_pass(const ldpc_code &c, LdsSchedule &sc, long *before, long *after) {
   place_variable_pass(c, sc, before, after, false);
