@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -137,9 +138,14 @@ static void place_variable_pass_search(const ldpc_code &c, LdsSchedule &sc, long
   };
   if (parts == 2) {
     std::vector<int> o0 = occ, o1 = occ;
-    std::thread other(search, 1, std::ref(o1));
+    std::thread other;
+    try {
+      other = std::thread(search, 1, std::ref(o1));
+    } catch (const std::system_error &) {      // no thread to be had: one after the other
+    }
     search(0, o0);
-    other.join();
+    if (other.joinable()) other.join();
+    else search(1, o1);
     for (int w = 0; w < W; w++) occ[w] = (tw[w] & 1) ? o1[w] : o0[w];
   } else {
     search(0, occ);
