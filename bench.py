@@ -335,6 +335,10 @@ CONFIG_LEGS = [
          iters=200, frames=1 << 16, batch=1 << 16, fused=True, b=4,
          what="32000.2240.3.105 binary32 min-sum (wide-row frame-resident kernel), exactly 13 flips per frame, <= 200 iterations, "
               "syndrome early exit"),
+    dict(id="configs[3]/MINSUM_F64", code="32000.2240.3.105.txt", alg="MINSUM_F64", dt="F64", channel="BSC_EXACT", p=13.0 / 32000,
+         iters=200, frames=1 << 14, batch=1 << 14, fused=False, b=8,
+         what="32000.2240.3.105 min-sum in the reference's binary64 (256 KB of sums per frame: two-pass engine, spans sized to the "
+              "Infinity Cache), exactly 13 flips per frame, <= 200 iterations, syndrome early exit"),
     dict(id="configs[2]/MINSUM_F32", code="dvb_H_0.5.txt", alg="MINSUM_F32", dt="F32", channel="AWGN", ebn0=2.4, iters=50,
          frames=4096, batch=4096, fused=True, kernel="stair_f32", b=4,
          what="DVB-S2 rate 1/2 binary32 min-sum (staircase frame-resident kernel), Eb/N0 = 2.4 dB, <= 50 iterations, early exit",
