@@ -484,11 +484,11 @@ struct BinaryEngine : Engine {
   // stays in the 256 MB Infinity Cache moves 6.0 - 6.4 TB/s in their access shape against 4.9 TB/s from HBM
   // (tools/hbm_ceiling with 64 - 192 MiB buffers against 1 - 4 GiB): a large call is cut into
   // spans of about 240 MB of messages, each decoded to the end before the next starts.  PEG-16000: Q8.8 14.8 -> 17.5
-  // Gbit/s, binary32 7.7 -> 9.6, binary64 3.9 -> 4.9.  The float sum-product passes are bound by arithmetic and gain
-  // less (+2 ... +15 %); the table sum-product's persistent check kernel loses on small spans and is not cut.
+  // Gbit/s, binary32 7.7 -> 9.6, binary64 3.9 -> 4.9.  The sum-product passes are bound by arithmetic and gain
+  // less (+2 ... +15 %), provided a span still fills the GPU several times over (the floors below).
   // LDPC_HIP_PASS_MB overrides (0: never cut).
   int frames_per_span(int nframes) const {
-    double mb = ALG == ALG_TAB ? 0.0 : 240.0;
+    double mb = 240.0;
     if (const char *e = getenv("LDPC_HIP_PASS_MB")) mb = atof(e);
     if (mb <= 0.0) return nframes;
     const double per_frame = (double)E * sizeof(T);
@@ -498,8 +498,12 @@ struct BinaryEngine : Engine {
     // the sum-product check passes are bound by arithmetic: a span must still fill the GPU several times over
     // (32000.2240, 2 240 checks: 256-frame spans cost SPA_F64 8 %; PEG-16000, 1 600 checks: 640-frame spans gain 7 %),
     // so at least 10^6 check-frames per launch
-    if (ALG != ALG_MS && ALG != ALG_MSQ)
-      per0 = std::max(per0, ((1000000L + m - 1) / m + SF - 1) / SF * SF);
+    if (ALG != ALG_MS && ALG != ALG_MSQ) {
+      // (the table kernel runs one persistent workgroup per CU: 512-frame spans cost 32000.2240 17 %; from 4 x 10^6
+      // check-frames on nothing is lost and DVB-S2 0.5 / 4095.737 gain 8 %)
+      const long least = ALG == ALG_TAB ? 4000000L : 1000000L;
+      per0 = std::max(per0, ((least + m - 1) / m + SF - 1) / SF * SF);
+    }
     if (const char *e = getenv("LDPC_HIP_PASS_SLABS")) per0 = std::max(1L, (long)atoi(e)) * SF;   // (tuning)
     // (spans of exactly that size and a shorter last one: evening them out rounds up to whole slabs, and the measured
     // optimum is narrow -- PEG-16000 Q8.8: 2 560 frames per span 17.5 Gbit/s, 3 072 frames 16.5)

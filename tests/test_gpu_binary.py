@@ -328,7 +328,7 @@ def test_q88_on_shapes_the_fused_decoder_must_turn_down(hip, oracle, tmp_path, s
 
 
 @pytest.mark.parametrize("prec,F,it,sigma", [("q88", 1000, 15, 0.55), ("f32", 1000, 15, 0.55), ("f64", 1000, 15, 0.55),
-                                             ("spa32", 1000, 15, 0.55), ("spa64", 1000, 15, 0.55),
+                                             ("spa32", 1000, 15, 0.55), ("spa64", 1000, 15, 0.55), ("table", 1000, 15, 0.55),
                                              # enough frames and iterations for the two-stage early exit (>= 8 slabs, >= 16
                                              # iterations), few enough failures for its first stage to stop: the open frames
                                              # of every span are listed and decoded again as one batch
@@ -356,6 +356,9 @@ def test_two_pass_calls_cut_into_spans(hip, oracle, prec, F, it, sigma):
         inp = llr
         ref = run_oracle(oracle.dec_minsum, oc, inp, s, it)
         alg = hip.ALG.MINSUM_F64
+    elif prec == "table":
+        inp = llr                                                  # (put on the Q8.14 grid by the library, as test_spa_table checks)
+        alg = hip.ALG.SPA_TABLE_Q14
     else:
         inp = llr.astype(np.float32) if prec == "spa32" else llr
         alg = hip.ALG.SPA_F32 if prec == "spa32" else hip.ALG.SPA_F64
