@@ -323,7 +323,9 @@ CONFIG_LEGS = [
          frames=1 << 20, batch=1 << 18, fused=True, b=8,
          what="MacKay (204,102) min-sum in the reference's binary64, BPSK/AWGN Eb/N0 = 2 dB, <= 50 iterations, early exit"),
     dict(id="configs[2]/SPA_F64", code="dvb_H_0.5.txt", alg="SPA_F64", dt="F64", channel="AWGN", ebn0=1.0, iters=50,
-         frames=4096, batch=4096, fused=False, b=8,
+         frames=4096, batch=4096, fused=False, b=8, issue_kernel="cn_reg_kernel",
+         issue_note="a binary64 add / multiply / fma occupies the vector unit for 4 cycles against the 2 of the nominal peak: "
+                    "a stream of them tops out at 0.5 of it",
          what="DVB-S2 rate 1/2 (n = 64800) sum-product in the reference's binary64, Eb/N0 = 1.0 dB, <= 50 iterations, early exit"),
     dict(id="configs[2]/SPA_TABLE_Q14", code="dvb_H_0.5.txt", alg="SPA_TABLE_Q14", dt="I32", channel="AWGN", ebn0=1.0,
          iters=50, frames=4096, batch=4096, fused=False, b=4,
@@ -345,7 +347,7 @@ CONFIG_LEGS = [
          note="the check pass is bound by vector issue, the rebuild of the sums by its 127 barrier steps; its per-workgroup record rows move 14.3 MB per frame at 10 iterations ("
               "profiles/r03_stair_f32_counters.txt)"),
     dict(id="configs[4]", code="q4.sp.9000.6000.4500.1", alg="GF2P_WHT", dt="I32", channel=None, iters=10, frames=2048,
-         batch=2048, fused=False, b=4,
+         batch=2048, fused=False, b=4, issue_kernel="gf2p_cn",
          what="GF(4) q4.sp.9000.6000.4500.1 Walsh-Hadamard check nodes, 10 iterations executed, random priors resident"),
 ]
 
@@ -406,6 +408,7 @@ def run_config_leg(i, local_rank, child=False):
                     "avg_iterations": round(cnt["iterations"] / max(1, cnt["frames"]), 3),
                     "includes": "source, enc(), channel, dec() and classification, all on the device"})
     names = ["variable pass", "check pass", "frame-resident whole-decode kernel", "other"]
+    rec["_check_pass_avg_ms"] = float(ms_k[1]) / int(cnt_k[1]) if cnt_k[1] else None
     if cnt_k.sum() > 0:
         k = int(np.argmax(ms_k))
         avg_ms = float(ms_k[k]) / max(1, int(cnt_k[k]))
@@ -437,10 +440,12 @@ def config_counters(args):
     one rocprofv3 pass each over `bench.py --config-child i` (before the parent touches the GPU)."""
     out = {}
     for i, leg in enumerate(CONFIG_LEGS):
-        if not leg["fused"]:
+        if not leg["fused"] and "issue_kernel" not in leg:
             continue
         child = [sys.executable, os.path.abspath(__file__), "--config-child", str(i)]
-        c, src = live_counters(args, leg.get("kernel", "fused_"), child=child, passes=CONFIG_PMC_PASS)
+        # (two-pass legs whose check pass is bound by vector issue, not by its bytes: that kernel's own count)
+        c, src = live_counters(args, leg.get("kernel", "fused_") if leg["fused"] else leg["issue_kernel"], child=child,
+                               passes=CONFIG_PMC_PASS)
         out[i] = (c, src)
     return out
 
@@ -674,6 +679,20 @@ def main():
                 rec = {"config": CONFIG_LEGS[i]["id"], "error": f"{type(e).__name__}: {e}"}
             c, src = cfg_counters.get(i, (None, None))
             rl = rec.get("roofline")
+            cn_ms = rec.pop("_check_pass_avg_ms", None)
+            if rl and rl["bound"] == "hbm" and "issue_kernel" in CONFIG_LEGS[i]:
+                # the check pass of this leg against the vector-issue ceiling, beside the byte figure above
+                iss = {"kernel": CONFIG_LEGS[i]["issue_kernel"], "counters": src, "peak": VALU_PEAK_GINST,
+                       "unit": "G wave-instructions/s", "avg_launch_ms": None if cn_ms is None else round(cn_ms, 4)}
+                if c and c.get("SQ_INSTS_VALU") and cn_ms:
+                    ach = c["SQ_INSTS_VALU"] / (cn_ms * 1e-3) / 1e9
+                    iss.update({"valu_wave_instructions_per_launch": int(c["SQ_INSTS_VALU"]), "achieved": round(ach, 1),
+                                "frac": round(ach / VALU_PEAK_GINST, 4)})
+                    if c.get("SQ_WAVE_CYCLES"):
+                        iss["wait_any_share"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+                if "issue_note" in CONFIG_LEGS[i]:
+                    iss["note"] = CONFIG_LEGS[i]["issue_note"]
+                rl["check_pass_vector_issue"] = iss
             if rl and rl["bound"] == "valu":
                 rl["counters"] = src
                 if c and c.get("SQ_INSTS_VALU"):

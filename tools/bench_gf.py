@@ -27,6 +27,7 @@ def main():
     for name, alg, dt, tdt, F in cases:
         if want not in name + alg:
             continue
+        F = int(os.environ.get("BENCH_GF_FRAMES", F))      # (frames per call: sweeps)
         code = ldpc_amd.Code.from_alist(os.path.join(CODES, name))
         n, m, q = code.n, code.m, code.q
         gen = torch.Generator(device=dev)
