@@ -519,8 +519,9 @@ struct BinaryEngine : Engine {
     int per = frames_per_span(nframes);
     if (dt < 0 || dt > 3 || !llr || nframes > nslab_max * SF) per = nframes;   // (bad arguments: decode_once says so)
     int most = 0;
-    for (int f0 = 0; f0 < nframes; f0 += per) {
-      const int cnt = std::min(per, nframes - f0);
+    for (int f0 = 0, cnt = 0; f0 < nframes; f0 += cnt) {
+      cnt = std::min(per, nframes - f0);
+      if (nframes - f0 - cnt < per / 4) cnt = nframes - f0;      // (a short tail rides with the last span)
       bool stopped = false;
       const int rc = decode_once(cnt, per < nframes ? (const void *)((const char *)llr + (size_t)f0 * n * elt[dt]) : llr, dt,
                                  sy_in ? sy_in + (size_t)f0 * m : nullptr, max_iter, bits ? bits + (size_t)f0 * n : nullptr,
