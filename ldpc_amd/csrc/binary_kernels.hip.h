@@ -1175,11 +1175,12 @@ __global__ void init_state_kernel(int nslab, int V, int nframes, uint32_t *fail,
 // After a syndrome test of the hard decisions of iteration `it`: frames whose
 // fail bits stayed clear have converged at `it` (dec() returns 0 there).
 // ignore != 0 discards the test (the float decoders have no iteration-0 check).
-__global__ void mark_kernel(int nslab, int V, int nframes, int it, int ignore, uint32_t *fail,
-                            uint8_t *done, int32_t *iters, int32_t *remaining) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void mark_kernel(int nslab, int V, int nframes, int it, int ignore, uint32_t *fail,
+                                                    uint8_t *done, int32_t *iters, int32_t *remaining, int32_t *remaining_host) {
+  // one workgroup walks all lanes: the count of open frames is then a plain store -- to the device slot and, when
+  // the host polls it (early exit), straight into its pinned word: no copy packet between two iterations' kernels
   int rem = 0;
-  if (idx < nslab * 64) {
+  for (int idx = threadIdx.x; idx < nslab * 64; idx += blockDim.x) {
     const unsigned f = fail[idx];
     fail[idx] = 0;
     unsigned d = done[idx];
@@ -1193,17 +1194,17 @@ __global__ void mark_kernel(int nslab, int V, int nframes, int it, int ignore, u
         done[idx] = (uint8_t)d;
       }
     }
-    rem = __popc(~d & all);
+    rem += __popc(~d & all);
   }
-  // block reduction -> one atomic per block
   for (int o = 32; o > 0; o >>= 1) rem += __shfl_down(rem, o);
-  __shared__ int part[4];
+  __shared__ int part[16];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rem;
   __syncthreads();
   if (threadIdx.x == 0) {
     int tot = 0;
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += part[k];
-    if (tot) atomicAdd(remaining, tot);
+    *remaining = tot;
+    if (remaining_host) *(volatile int32_t *)remaining_host = tot;
   }
 }
 

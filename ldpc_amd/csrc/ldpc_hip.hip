@@ -455,11 +455,12 @@ struct BinaryEngine : Engine {
     return LDPC_OK;
   }
 
-  int launch_mark(int nslab, int nframes, int it, int ignore, int slot, hipStream_t st) {
-    const int threads = nslab * 64;
-    hipLaunchKernelGGL(mark_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, nslab, V, nframes, it,
+  // to_host: the count of open frames also goes straight into the pinned word the host polls (h_remaining[slot])
+  int launch_mark(int nslab, int nframes, int it, int ignore, int slot, hipStream_t st, bool to_host = false) {
+    const int threads = std::min(1024, (nslab * 64 + 63) / 64 * 64);
+    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(threads), 0, st, nslab, V, nframes, it,
                        ignore, fail.as<uint32_t>(), done.as<uint8_t>(), iters.as<int32_t>(),
-                       remaining.as<int32_t>() + slot);
+                       remaining.as<int32_t>() + slot, to_host ? h_remaining + slot : nullptr);
     LAUNCHCHK("mark_kernel");
     return LDPC_OK;
   }
@@ -636,11 +637,9 @@ struct BinaryEngine : Engine {
       // the check pass tested the decisions of iteration t-1; only the Q8.8
       // decoder has an iteration-0 test (_fixed.c:198-207)
       const int ignore = (t == 1 && ALG != ALG_MSQ) ? 1 : 0;
-      if ((rc = launch_mark(nslab, nframes, t - 1, ignore, t - 1, st))) return rc;
+      if ((rc = launch_mark(nslab, nframes, t - 1, ignore, t - 1, st, early))) return rc;
       executed = t;
       if (early) {
-        HIPCHK(hipMemcpyAsync(h_remaining + (t - 1), remaining.as<int32_t>() + (t - 1), sizeof(int32_t),
-                              hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(ev[(t - 1) % EV_RING], st));
         if (t >= 2) {
           HIPCHK(hipEventSynchronize(ev[(t - 2) % EV_RING]));
